@@ -1,0 +1,138 @@
+"""Deterministic synthetic weights / inputs for the DDP hot path.
+
+No checkpoints or datasets are reachable offline, so tests, ``bench.py`` and the golden-vector
+generator all draw the *same* seeded tensors from here.  Key names and shapes follow the
+reference ``state_dict`` layout (probe of
+``segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py``) so that a dict produced here
+loads into the reference model with ``load_state_dict`` and into ``ddp_amd``'s drop-in classes
+unchanged.
+
+The reference's own initialisation is degenerate for testing
+(``MultiScaleDeformableAttention.init_weights`` zeroes ``sampling_offsets.weight`` and
+``attention_weights.*``; controlnet/annotator/uniformer/mmcv/ops/multi_scale_deform_attn.py:230-247),
+so every term is given a non-trivial seeded value instead: offsets move a few pixels, attention
+logits are O(1), LayerNorm affine is perturbed.
+"""
+import math
+
+import torch
+
+EMBED = 256
+HEADS = 8
+POINTS = 4
+FFN = 1024
+TIME_DIM = 1024
+SINU_DIM = 16
+
+
+def _uniform(gen, shape, bound):
+    return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * bound
+
+
+def _normal(gen, shape, mean=0.0, std=1.0):
+    return torch.randn(shape, generator=gen, dtype=torch.float32) * std + mean
+
+
+def _xavier(gen, out_f, in_f, *extra):
+    fan_in = in_f
+    fan_out = out_f
+    for e in extra:
+        fan_in *= e
+        fan_out *= e
+    bound = math.sqrt(6.0 / (fan_in + fan_out))
+    return _uniform(gen, (out_f, in_f) + tuple(extra), bound)
+
+
+def _offset_ring_bias():
+    """sampling_offsets.bias of the reference init: per-head direction ring of radius 1..4 px
+    (multi_scale_deform_attn.py:233-244)."""
+    thetas = torch.arange(HEADS, dtype=torch.float32) * (2.0 * math.pi / HEADS)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(HEADS, 1, 1, 2).repeat(1, 1, POINTS, 1)
+    for i in range(POINTS):
+        grid[:, :, i, :] *= i + 1
+    return grid.reshape(-1)
+
+
+def encoder_layer_state(gen, prefix, sd):
+    a = prefix + 'attentions.0.'
+    sd[a + 'sampling_offsets.weight'] = _normal(gen, (HEADS * POINTS * 2, EMBED), std=0.02)
+    sd[a + 'sampling_offsets.bias'] = _offset_ring_bias() + _normal(gen, (HEADS * POINTS * 2,), std=0.3)
+    sd[a + 'attention_weights.weight'] = _normal(gen, (HEADS * POINTS, EMBED), std=0.05)
+    sd[a + 'attention_weights.bias'] = _normal(gen, (HEADS * POINTS,), std=1.0)
+    sd[a + 'value_proj.weight'] = _xavier(gen, EMBED, EMBED)
+    sd[a + 'value_proj.bias'] = _normal(gen, (EMBED,), std=0.02)
+    sd[a + 'output_proj.weight'] = _xavier(gen, EMBED, EMBED)
+    sd[a + 'output_proj.bias'] = _normal(gen, (EMBED,), std=0.02)
+    sd[prefix + 'time_mlp.1.weight'] = _uniform(gen, (2 * EMBED, TIME_DIM), 1.0 / math.sqrt(TIME_DIM))
+    sd[prefix + 'time_mlp.1.bias'] = _uniform(gen, (2 * EMBED,), 1.0 / math.sqrt(TIME_DIM))
+    sd[prefix + 'ffns.0.layers.0.0.weight'] = _xavier(gen, FFN, EMBED)
+    sd[prefix + 'ffns.0.layers.0.0.bias'] = _normal(gen, (FFN,), std=0.02)
+    sd[prefix + 'ffns.0.layers.1.weight'] = _xavier(gen, EMBED, FFN)
+    sd[prefix + 'ffns.0.layers.1.bias'] = _normal(gen, (EMBED,), std=0.02)
+    for n in (0, 1):
+        sd[prefix + f'norms.{n}.weight'] = _normal(gen, (EMBED,), mean=1.0, std=0.1)
+        sd[prefix + f'norms.{n}.bias'] = _normal(gen, (EMBED,), std=0.1)
+
+
+def time_mlp_state(gen, sd):
+    sd['time_mlp.0.weights'] = _normal(gen, (SINU_DIM // 2,))
+    sd['time_mlp.1.weight'] = _uniform(gen, (TIME_DIM, SINU_DIM + 1), 1.0 / math.sqrt(SINU_DIM + 1))
+    sd['time_mlp.1.bias'] = _uniform(gen, (TIME_DIM,), 1.0 / math.sqrt(SINU_DIM + 1))
+    sd['time_mlp.3.weight'] = _uniform(gen, (TIME_DIM, TIME_DIM), 1.0 / math.sqrt(TIME_DIM))
+    sd['time_mlp.3.bias'] = _uniform(gen, (TIME_DIM,), 1.0 / math.sqrt(TIME_DIM))
+
+
+def make_state_dict(task='seg', num_classes=150, num_layers=6, feat_channels=256, seed=2):
+    """Hot-path ``state_dict`` (CPU fp32) for ``task`` in {'seg', 'depth', 'bev'}.
+
+    seg  : segmentation/mmseg/models/segmentors/ddp.py:78,92-112 + decode head
+    depth: depth/depth/models/depther/ddp.py:70-91 (``down`` conv over 256+1 channels, 3x3 ``conv_depth``)
+    bev  : bev/mmdet3d/models/fusion_models/ddp.py:91,104-114 (``transform`` over 256+feat_channels,
+           embedding (7,256)); head keys are given the ``decode_head.`` prefix here as well.
+    """
+    gen = torch.Generator(device='cpu')
+    gen.manual_seed(int(seed))
+    sd = {}
+    if task == 'depth':
+        cin = feat_channels + 1
+        sd['down.conv.weight'] = _xavier(gen, EMBED, cin, 1, 1)
+        sd['down.conv.bias'] = _normal(gen, (EMBED,), std=0.02)
+    else:
+        cin = feat_channels + EMBED
+        sd['transform.conv.weight'] = _xavier(gen, EMBED, cin, 1, 1)
+        sd['transform.conv.bias'] = _normal(gen, (EMBED,), std=0.02)
+    time_mlp_state(gen, sd)
+    if task != 'depth':
+        sd['embedding_table.weight'] = _normal(gen, (num_classes + 1, EMBED))
+    for l in range(num_layers):
+        encoder_layer_state(gen, f'decode_head.encoder.layers.{l}.', sd)
+    if task == 'depth':
+        sd['decode_head.conv_depth.weight'] = _xavier(gen, 1, EMBED, 3, 3) * 4.0
+        sd['decode_head.conv_depth.bias'] = _normal(gen, (1,), mean=2.0, std=0.1)
+    else:
+        sd['decode_head.conv_seg.weight'] = _xavier(gen, num_classes, EMBED, 1, 1)
+        sd['decode_head.conv_seg.bias'] = _normal(gen, (num_classes,), std=0.02)
+    return sd
+
+
+def make_inputs(batch, h, w, randsteps=1, feat_channels=256, noise_channels=256, seed=0):
+    """Synthetic frozen feature ``x`` (B,Cx,h,w) ~ N(0,1) and start noise (B,r,Cm,h,w) ~ N(0,1)
+    (FPN+GN output is roughly unit scale)."""
+    gx = torch.Generator(device='cpu')
+    gx.manual_seed(int(seed))
+    x = torch.randn((batch, feat_channels, h, w), generator=gx, dtype=torch.float32)
+    gn = torch.Generator(device='cpu')
+    gn.manual_seed(int(seed) + 1)
+    noise = torch.randn((batch, randsteps, noise_channels, h, w), generator=gn, dtype=torch.float32)
+    return x, noise
+
+
+def checksum(sd):
+    """Order-independent fingerprint of a state dict (stored in golden fixtures to detect drift of
+    the seeded generator across torch versions)."""
+    tot = 0.0
+    for k in sorted(sd):
+        v = sd[k].double()
+        tot += float(v.sum()) + 0.5 * float(v.abs().sum())
+    return tot

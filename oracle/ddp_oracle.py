@@ -1,0 +1,412 @@
+"""CPU ORACLE for the DDP multi-step denoising inference loop.  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A functional, mmcv-free restatement (torch CPU fp32 ops) of the reference's hot path.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module - and only as the checker / the CPU baseline, never as the thing shipped: ``ddp_amd``
+(the product) never imports it and fails loudly when its HIP library is missing.
+
+PARITY PIN.  The reference holds no tests, golden vectors or fixtures for this path (SURVEY.md
+§4, §8c: "parity unpinned" by the reference's own tests).  The oracle is therefore pinned against
+outputs of the reference itself, imported in the build container through
+``tests/golden/ref_shim.py`` and run on seeded inputs by ``tests/golden/gen_golden.py``; the
+resulting vectors are committed under ``tests/golden/*.npz`` and
+``tests/test_oracle_golden.py`` checks this file against every one of them (plus the
+known-answer values of the schedule and positional encoding recorded in SURVEY.md §3.2/§8 a9).
+Caveat recorded with the fixtures: the reference's arithmetic core lives in the third-party
+mmcv-full==1.6.2 (segmentation/README.md:25) which is not vendored; the import used the in-tree
+pure-python mmcv 1.3.17 (controlnet/annotator/uniformer/mmcv) on torch 2.10 CPU.
+
+Every function cites the reference lines it follows.  Paths are relative to /root/reference;
+``MSDA`` = controlnet/annotator/uniformer/mmcv/ops/multi_scale_deform_attn.py,
+``XFMR`` = segmentation/mmseg/models/utils/transformer.py,
+``SEGDDP`` = segmentation/mmseg/models/segmentors/ddp.py,
+``DHWT`` = segmentation/mmseg/models/decode_heads/deformable_head_with_time.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EMBED = 256
+HEADS = 8
+POINTS = 4
+
+
+# --------------------------------------------------------------------------------------------
+# schedules  (SEGDDP:14-28; depth/depth/models/depther/ddp.py:207-208)
+# --------------------------------------------------------------------------------------------
+def log_clamped(t, eps=1e-20):
+    """SEGDDP:14-15."""
+    return torch.log(t.clamp(min=eps))
+
+
+def beta_linear_log_snr(t):
+    """SEGDDP:18-19."""
+    return -torch.log(torch.special.expm1(1e-4 + 10 * (t ** 2)))
+
+
+def alpha_cosine_log_snr(t, ns=0.0002, ds=0.00025):
+    """SEGDDP:22-24.  Evaluated in fp32 in exactly this op order: the value at t=1 is
+    ill-conditioned (SURVEY.md §7 hard part 8)."""
+    return -log_clamped((torch.cos((t + ns) / (1 + ds) * math.pi * 0.5) ** -2) - 1, eps=1e-5)
+
+
+def log_snr_to_alpha_sigma(log_snr):
+    """SEGDDP:27-28."""
+    return torch.sqrt(torch.sigmoid(log_snr)), torch.sqrt(torch.sigmoid(-log_snr))
+
+
+def gamma_cosine(t, ns=0.0002, ds=0.00025):
+    """depth/depth/models/depther/ddp.py:207-208."""
+    return torch.cos(((t + ns) / (1 + ds)) * math.pi / 2) ** 2
+
+
+def sampling_time_pairs(timesteps, time_difference=1, sample_range0=0.0):
+    """SEGDDP:204-213 (depth/bev: same with sample_range0 == 0).  -> list of (t_now, t_next)
+    python floats; the reference wraps them in torch.tensor([t_now, t_next]) (fp32)."""
+    pairs = []
+    for step in range(timesteps):
+        t_now = 1 - (step / timesteps) * (1 - sample_range0)
+        t_next = max(1 - (step + 1 + time_difference) / timesteps * (1 - sample_range0), sample_range0)
+        pairs.append((t_now, t_next))
+    return pairs
+
+
+# --------------------------------------------------------------------------------------------
+# time embedding + per-layer FiLM  (SEGDDP:31-46,107-112; XFMR:275-278,413-417)
+# --------------------------------------------------------------------------------------------
+def learned_sinusoidal(x, weights):
+    """SEGDDP:41-46.  x (r,) -> (r, 17): [x, sin(2 pi x w), cos(2 pi x w)]."""
+    x = x[:, None]
+    freqs = x * weights[None, :] * 2 * math.pi
+    return torch.cat((x, freqs.sin(), freqs.cos()), dim=-1)
+
+
+def time_mlp(t_in, sd):
+    """SEGDDP:107-112: Linear(17,1024) -> GELU(erf) -> Linear(1024,1024)."""
+    u = learned_sinusoidal(t_in, sd['time_mlp.0.weights'])
+    hid = F.gelu(F.linear(u, sd['time_mlp.1.weight'], sd['time_mlp.1.bias']))
+    return F.linear(hid, sd['time_mlp.3.weight'], sd['time_mlp.3.bias'])
+
+
+def film_vectors(temb, sd, layer):
+    """XFMR:275-278,413-416: Linear(1024,512)(SiLU(temb)) -> (scale, shift) each (r,256)."""
+    p = f'decode_head.encoder.layers.{layer}.time_mlp.1.'
+    g = F.linear(F.silu(temb), sd[p + 'weight'], sd[p + 'bias'])
+    return g[:, :EMBED], g[:, EMBED:]
+
+
+# --------------------------------------------------------------------------------------------
+# positional encoding / reference points  (XFMR:78-113; DHWT:63-88)
+# --------------------------------------------------------------------------------------------
+def sine_positional_encoding(h, w, num_feats=128, temperature=10000, scale=2 * math.pi, eps=1e-6,
+                             offset=-0.5):
+    """XFMR:78-113 with normalize=True and an all-valid mask.  -> (256, h, w)."""
+    ones = torch.ones((1, h, w), dtype=torch.int)
+    y_embed = ones.cumsum(1, dtype=torch.float32)
+    x_embed = ones.cumsum(2, dtype=torch.float32)
+    y_embed = (y_embed + offset) / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = (x_embed + offset) / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(1, h, w, -1)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(1, h, w, -1)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)[0]
+
+
+def reference_points(h, w):
+    """DHWT:63-88 for a single level.  -> (N, 2) as (x, y) in [0,1]."""
+    ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=torch.float32),
+                                  torch.linspace(0.5, w - 0.5, w, dtype=torch.float32), indexing='ij')
+    return torch.stack((ref_x.reshape(-1) / w, ref_y.reshape(-1) / h), -1)
+
+
+# --------------------------------------------------------------------------------------------
+# deformable attention  (MSDA:94-151 core, MSDA:299-358 module forward)
+# --------------------------------------------------------------------------------------------
+def msda_core_gridsample(value, h, w, sampling_locations, attention_weights):
+    """MSDA:94-151 (``multi_scale_deformable_attn_pytorch``) for one level.
+    value (bs, N, heads, d); sampling_locations (bs, Nq, heads, P, 2) in [0,1];
+    attention_weights (bs, Nq, heads, P) -> (bs, Nq, heads*d)."""
+    bs, n, heads, d = value.shape
+    nq = sampling_locations.shape[1]
+    grids = 2 * sampling_locations - 1
+    value_l = value.flatten(2).transpose(1, 2).reshape(bs * heads, d, h, w)
+    grid_l = grids.transpose(1, 2).flatten(0, 1)                      # (bs*heads, Nq, P, 2)
+    sampled = F.grid_sample(value_l, grid_l, mode='bilinear', padding_mode='zeros', align_corners=False)
+    aw = attention_weights.transpose(1, 2).reshape(bs * heads, 1, nq, POINTS)
+    out = (sampled * aw).sum(-1).view(bs, heads * d, nq)
+    return out.transpose(1, 2).contiguous()
+
+
+def msda_core_taps(value, h, w, px, py, attention_weights):
+    """Independent restatement of the same sampling with explicit 4-corner bilinear taps in PIXEL
+    units (for a single level the sample point of token (i,j) is simply
+    (j + o_x, i + o_y); taps outside [0,w-1]x[0,h-1] contribute 0).  px, py (bs,Nq,heads,P)."""
+    bs, n, heads, d = value.shape
+    x0 = torch.floor(px)
+    y0 = torch.floor(py)
+    fx = px - x0
+    fy = py - y0
+    out = torch.zeros(bs, px.shape[1], heads, d)
+    vb = value.permute(0, 2, 1, 3)                                     # (bs, heads, N, d)
+    for dy, dx, wgt in ((0, 0, (1 - fy) * (1 - fx)), (0, 1, (1 - fy) * fx),
+                        (1, 0, fy * (1 - fx)), (1, 1, fy * fx)):
+        xi = (x0 + dx).long()
+        yi = (y0 + dy).long()
+        valid = ((xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)).float()
+        idx = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1))              # (bs,Nq,heads,P)
+        coef = wgt * valid * attention_weights
+        for p in range(POINTS):
+            ind = idx[..., p].permute(0, 2, 1)                           # (bs, heads, Nq)
+            g = torch.gather(vb, 2, ind[..., None].expand(-1, -1, -1, d))  # (bs, heads, Nq, d)
+            out += g.permute(0, 2, 1, 3) * coef[..., p][..., None]
+    return out.reshape(bs, px.shape[1], heads * d)
+
+
+def msda_forward(q, pos, h, w, sd, prefix, core='gridsample'):
+    """MSDA:299-358 with batch_first=False folded away: q (bs,N,256) token-major, pos (N,256).
+    value from q WITHOUT pos; offsets / attention logits from q+pos; residual = q; dropout p=0."""
+    bs, n, _ = q.shape
+    qp = q + pos[None]
+    value = F.linear(q, sd[prefix + 'value_proj.weight'], sd[prefix + 'value_proj.bias'])
+    value = value.view(bs, n, HEADS, -1)
+    off = F.linear(qp, sd[prefix + 'sampling_offsets.weight'], sd[prefix + 'sampling_offsets.bias'])
+    off = off.view(bs, n, HEADS, POINTS, 2)
+    aw = F.linear(qp, sd[prefix + 'attention_weights.weight'], sd[prefix + 'attention_weights.bias'])
+    aw = aw.view(bs, n, HEADS, POINTS).softmax(-1)
+    if core == 'gridsample':
+        ref = reference_points(h, w)                                    # (N,2)
+        normalizer = torch.tensor([w, h], dtype=torch.float32)          # MSDA:330-331 (w, h)
+        loc = ref[None, :, None, None, :] + off / normalizer
+        s = msda_core_gridsample(value, h, w, loc, aw)
+    else:
+        jj = torch.arange(w, dtype=torch.float32).repeat(h)
+        ii = torch.arange(h, dtype=torch.float32).repeat_interleave(w)
+        px = jj[None, :, None, None] + off[..., 0]
+        py = ii[None, :, None, None] + off[..., 1]
+        s = msda_core_taps(value, h, w, px, py, aw)
+    out = F.linear(s, sd[prefix + 'output_proj.weight'], sd[prefix + 'output_proj.bias'])
+    return out + q
+
+
+def encoder_layer(q, pos, temb, h, w, sd, layer, core='gridsample'):
+    """XFMR:317-419 with operation_order ('self_attn','norm','ffn','norm') + FiLM (XFMR:413-417);
+    FFN = controlnet/annotator/uniformer/mmcv/cnn/bricks/transformer.py:269-280."""
+    p = f'decode_head.encoder.layers.{layer}.'
+    y = msda_forward(q, pos, h, w, sd, p + 'attentions.0.', core)
+    q1 = F.layer_norm(y, (EMBED,), sd[p + 'norms.0.weight'], sd[p + 'norms.0.bias'], 1e-5)
+    hid = F.gelu(F.linear(q1, sd[p + 'ffns.0.layers.0.0.weight'], sd[p + 'ffns.0.layers.0.0.bias']))
+    y2 = q1 + F.linear(hid, sd[p + 'ffns.0.layers.1.weight'], sd[p + 'ffns.0.layers.1.bias'])
+    q2 = F.layer_norm(y2, (EMBED,), sd[p + 'norms.1.weight'], sd[p + 'norms.1.bias'], 1e-5)
+    if temb is not None and (p + 'time_mlp.1.weight') in sd:
+        scale, shift = film_vectors(temb, sd, layer)
+        q2 = q2 * (scale[:, None, :] + 1) + shift[:, None, :]
+    return q2
+
+
+def num_layers_of(sd):
+    n = 0
+    while f'decode_head.encoder.layers.{n}.norms.0.weight' in sd:
+        n += 1
+    return n
+
+
+def encoder_forward(feat, temb, sd, core='gridsample', trace=None):
+    """DHWT:90-128: flatten NCHW -> tokens, sine pos-enc, L layers.  feat (bs,256,h,w) ->
+    memory (bs, N, 256) token-major."""
+    bs, c, h, w = feat.shape
+    pos = sine_positional_encoding(h, w).flatten(1).transpose(0, 1)      # (N,256)
+    q = feat.flatten(2).transpose(1, 2)                                  # (bs,N,256)
+    for l in range(num_layers_of(sd)):
+        q = encoder_layer(q, pos, temb, h, w, sd, l, core)
+        if trace is not None:
+            trace.append(q.clone())
+    return q
+
+
+def head_forward_seg(feat, temb, sd, core='gridsample', trace=None):
+    """DHWT:90-132: encoder then conv_seg (1x1, dropout bypassed).  -> logits (bs,K,h,w)."""
+    bs, c, h, w = feat.shape
+    mem = encoder_forward(feat, temb, sd, core, trace)
+    mem = mem.permute(0, 2, 1).reshape(bs, c, h, w).contiguous()
+    return F.conv2d(mem, sd['decode_head.conv_seg.weight'], sd['decode_head.conv_seg.bias'])
+
+
+def head_forward_depth(feat, temb, sd, min_depth=1e-3, core='gridsample', trace=None):
+    """depth/depth/models/decode_heads/deformable_head_with_time.py:90-131 +
+    depth/depth/models/decode_heads/decode_head.py:100,264-269 (scale_up=False, use_eps=True):
+    relu(conv3x3(memory)) + min_depth."""
+    bs, c, h, w = feat.shape
+    mem = encoder_forward(feat, temb, sd, core, trace)
+    mem = mem.permute(0, 2, 1).reshape(bs, c, h, w).contiguous()
+    d = F.conv2d(mem, sd['decode_head.conv_depth.weight'], sd['decode_head.conv_depth.bias'], padding=1)
+    return F.relu(d) + min_depth
+
+
+# --------------------------------------------------------------------------------------------
+# samplers
+# --------------------------------------------------------------------------------------------
+def x0_from_logits_seg(logits, sd, bit_scale):
+    """SEGDDP:235-237: argmax -> embedding -> (sigmoid*2-1)*bit_scale.  (r,K,h,w)->(r,256,h,w)."""
+    idx = torch.argmax(logits, dim=1)
+    e = F.embedding(idx, sd['embedding_table.weight']).permute(0, 3, 1, 2)
+    return (torch.sigmoid(e) * 2 - 1) * bit_scale
+
+
+def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time_difference=1,
+                    sample_range0=0.0, noise_schedule='cosine', accumulation=False,
+                    core='gridsample', trace=None):
+    """SEGDDP:215-246 for ONE image.  x (1,256,h,w); noise (r,256,h,w) replaces the in-method
+    ``torch.randn`` (SEGDDP:220).  -> (1,K,h,w)."""
+    log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
+    xr = x.repeat(randsteps, 1, 1, 1)
+    mask_t = noise.clone()
+    outs = []
+    logits = None
+    for t_now, t_next in sampling_time_pairs(timesteps, time_difference, sample_range0):
+        times_now = torch.tensor([t_now], dtype=torch.float32)
+        times_next = torch.tensor([t_next], dtype=torch.float32)
+        feat = torch.cat([xr, mask_t], dim=1)
+        feat = F.conv2d(feat, sd['transform.conv.weight'], sd['transform.conv.bias'])
+        log_snr = log_snr_fn(times_now)
+        log_snr_next = log_snr_fn(times_next)
+        alpha, sigma = log_snr_to_alpha_sigma(log_snr.view(-1, 1, 1, 1))
+        alpha_next, sigma_next = log_snr_to_alpha_sigma(log_snr_next.view(-1, 1, 1, 1))
+        temb = time_mlp(log_snr, sd)
+        layer_trace = [] if trace is not None else None
+        logits = head_forward_seg(feat, temb, sd, core, layer_trace)
+        x0 = x0_from_logits_seg(logits, sd, bit_scale)
+        pred_noise = (mask_t - alpha * x0) / sigma.clamp(min=1e-8)
+        mask_t = x0 * alpha_next + pred_noise * sigma_next
+        if accumulation:
+            outs.append(logits.softmax(1))
+        if trace is not None:
+            trace.append(dict(feat=feat, temb=temb, layers=layer_trace, logits=logits, mask_t=mask_t.clone()))
+    if accumulation:
+        logits = torch.cat(outs, dim=0)
+    return logits.mean(dim=0, keepdim=True)
+
+
+def ddpm_sample_seg(x, noise, step_noise, sd, timesteps=3, randsteps=1, bit_scale=0.01,
+                    time_difference=1, sample_range0=0.0, noise_schedule='cosine', accumulation=False,
+                    core='gridsample'):
+    """SEGDDP:248-290.  ``step_noise`` (timesteps, r,256,h,w) replaces the per-step
+    ``torch.randn_like`` (SEGDDP:280)."""
+    log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
+    xr = x.repeat(randsteps, 1, 1, 1)
+    mask_t = noise.clone()
+    outs = []
+    logits = None
+    for s, (t_now, t_next) in enumerate(sampling_time_pairs(timesteps, time_difference, sample_range0)):
+        times_now = torch.tensor([t_now], dtype=torch.float32)
+        times_next = torch.tensor([t_next], dtype=torch.float32)
+        feat = F.conv2d(torch.cat([xr, mask_t], dim=1), sd['transform.conv.weight'], sd['transform.conv.bias'])
+        log_snr = log_snr_fn(times_now)
+        log_snr_next = log_snr_fn(times_next)
+        pl = log_snr.view(-1, 1, 1, 1)
+        pln = log_snr_next.view(-1, 1, 1, 1)
+        alpha, sigma = log_snr_to_alpha_sigma(pl)
+        alpha_next, sigma_next = log_snr_to_alpha_sigma(pln)
+        temb = time_mlp(log_snr, sd)
+        logits = head_forward_seg(feat, temb, sd, core)
+        x0 = x0_from_logits_seg(logits, sd, bit_scale)
+        # times carry the image batch b == 1 (SEGDDP:204-212), so every schedule quantity is a
+        # single scalar broadcast over the r noise replicas.
+        c = -torch.special.expm1(pl - pln)
+        mean = alpha_next * (mask_t * (1 - c) / alpha + c * x0)
+        variance = (sigma_next ** 2) * c
+        log_variance = log_clamped(variance)
+        nz = step_noise[s] if t_next > 0 else torch.zeros_like(mask_t)
+        mask_t = mean + (0.5 * log_variance).exp() * nz
+        if accumulation:
+            outs.append(logits.softmax(1))
+    if accumulation:
+        logits = torch.cat(outs, dim=0)
+    return logits.mean(dim=0, keepdim=True)
+
+
+def sample_depth(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.1, time_difference=1,
+                 min_depth=1e-3, max_depth=80.0, core='gridsample', trace=None):
+    """depth/depth/models/depther/ddp.py:229-247 (+ ddim_step :220-227) for ONE image.
+    x (1,256,h,w); noise (r,1,h,w).  -> (1,1,h,w) metric depth (before the encode_decode clamp)."""
+    xr = x.repeat(randsteps, 1, 1, 1)
+    depth_t = noise.clone()
+    depth_pred = None
+    for t_now, t_next in sampling_time_pairs(timesteps, time_difference, 0.0):
+        times_now = torch.tensor([t_now], dtype=torch.float32)
+        times_next = torch.tensor([t_next], dtype=torch.float32)
+        feat = F.conv2d(torch.cat([xr, depth_t], dim=1), sd['down.conv.weight'], sd['down.conv.bias'])
+        temb = time_mlp(times_now, sd)                                   # raw t, not log-snr (:238)
+        depth_pred = head_forward_depth(feat, temb, sd, min_depth, core)
+        x0 = (depth_pred - min_depth) / (max_depth - min_depth)
+        x0 = (x0 * 2 - 1) * bit_scale
+        a_now = gamma_cosine(times_now.view(-1, 1, 1, 1))
+        a_next = gamma_cosine(times_next.view(-1, 1, 1, 1))
+        x0 = x0.clamp(-bit_scale, bit_scale)
+        eps = (1 / (1 - a_now).sqrt()) * (depth_t - a_now.sqrt() * x0)
+        depth_t = a_next.sqrt() * x0 + (1 - a_next).sqrt() * eps
+        if trace is not None:
+            trace.append(dict(feat=feat, temb=temb, depth_pred=depth_pred, depth_t=depth_t.clone()))
+    return depth_pred.mean(dim=0, keepdim=True)
+
+
+# --------------------------------------------------------------------------------------------
+# BEV  (bev/mmdet3d/models/heads/segm/deformable_head_with_time.py:57-97,179-235;
+#       bev/mmdet3d/models/fusion_models/ddp.py:268-301)
+# --------------------------------------------------------------------------------------------
+def bev_grid_transform(feat, input_scope=((-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8)),
+                       output_scope=((-50, 50, 0.5), (-50, 50, 0.5))):
+    """BEVGridTransform.forward, bev/.../heads/segm/deformable_head_with_time.py:70-97."""
+    coords = []
+    for (imin, imax, _), (omin, omax, ostep) in zip(input_scope, output_scope):
+        v = torch.arange(omin + ostep / 2, omax, ostep)
+        v = (v - imin) / (imax - imin) * 2 - 1
+        coords.append(v)
+    u, v = torch.meshgrid(coords, indexing='ij')
+    grid = torch.stack([v, u], dim=-1)
+    grid = torch.stack([grid] * feat.shape[0], dim=0)
+    return F.grid_sample(feat, grid, mode='bilinear', align_corners=False)
+
+
+def head_forward_bev(feat, temb, sd, core='gridsample', **scopes):
+    """bev/.../heads/segm/deformable_head_with_time.py:179-235: grid transform, encoder at the
+    output resolution, conv_seg 1x1, sigmoid."""
+    ft = bev_grid_transform(feat, **scopes)
+    bs, c, h, w = ft.shape
+    mem = encoder_forward(ft, temb, sd, core)
+    mem = mem.permute(0, 2, 1).reshape(bs, c, h, w).contiguous()
+    out = F.conv2d(mem, sd['decode_head.conv_seg.weight'], sd['decode_head.conv_seg.bias'])
+    return torch.sigmoid(out)
+
+
+def ddim_sample_bev(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time_difference=1,
+                    threshold=0.5, num_classes=6, core='gridsample', **scopes):
+    """bev/mmdet3d/models/fusion_models/ddp.py:268-301 for ONE sample.  x (1,Cx,h,w); noise
+    (r,256,h,w).  -> (1,6,H_out,W_out) mean over steps*r of sigmoid maps."""
+    h, w = x.shape[-2:]
+    xr = x.repeat(randsteps, 1, 1, 1)
+    mask_t = noise.clone()
+    outs = []
+    for t_now, t_next in sampling_time_pairs(timesteps, time_difference, 0.0):
+        times_now = torch.tensor([t_now], dtype=torch.float32)
+        times_next = torch.tensor([t_next], dtype=torch.float32)
+        feat = F.conv2d(torch.cat([xr, mask_t], dim=1), sd['transform.conv.weight'], sd['transform.conv.bias'])
+        log_snr = alpha_cosine_log_snr(times_now)
+        log_snr_next = alpha_cosine_log_snr(times_next)
+        alpha, sigma = log_snr_to_alpha_sigma(log_snr.view(-1, 1, 1, 1))
+        alpha_next, sigma_next = log_snr_to_alpha_sigma(log_snr_next.view(-1, 1, 1, 1))
+        temb = time_mlp(log_snr, sd)
+        prob = head_forward_bev(feat, temb, sd, core, **scopes)
+        pred = (prob > threshold)
+        factor = (torch.arange(num_classes) + 1).view(1, num_classes, 1, 1)
+        pred = pred * factor
+        pred = F.interpolate(pred.float(), size=(h, w), mode='nearest').to(torch.int64)
+        e = F.embedding(pred, sd['embedding_table.weight']).mean(dim=1).permute(0, 3, 1, 2)
+        x0 = (torch.sigmoid(e) * 2 - 1) * bit_scale
+        pred_noise = (mask_t - alpha * x0) / sigma.clamp(min=1e-8)
+        mask_t = x0 * alpha_next + pred_noise * sigma_next
+        outs.append(prob)
+    return torch.cat(outs, dim=0).mean(dim=0, keepdim=True)

@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""Generate golden vectors for the DDP hot path FROM THE REFERENCE ITSELF.
+
+Run by hand in the build container (needs /root/reference):
+
+    python tests/golden/gen_golden.py            # all tasks, one subprocess each
+    python tests/golden/gen_golden.py --task seg
+
+The reference packages are imported through ``ref_shim`` (mmcv 1.3.17 python bricks vendored in
+the reference tree, torch CPU fp32), the seeded synthetic hot-path weights of
+``ddp_amd.utils.synthetic`` are loaded with ``load_state_dict`` and the in-method ``torch.randn``
+is replaced by the seeded start noise, so that the oracle / HIP path can be fed bit-identical
+inputs.  Only *data* is written: per case one ``tests/golden/<case>.npz`` holding the config, the
+input fingerprints and the reference outputs (final output, per-step logits / noisy map, and a few
+per-layer activations for the smallest case).  Inputs and weights are NOT stored - they are
+regenerated from the seeds (the fingerprints guard against generator drift).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from ddp_amd.utils import synthetic  # noqa: E402
+
+SEG_CASES = [
+    # ADE-like: 150 classes, accumulation (configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py:13-15)
+    dict(name='seg_ade_k3', h=16, w=24, num_classes=150, timesteps=3, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=0, trace=False),
+    # Cityscapes-like: 19 classes, no accumulation, odd map size, two noise replicas, full trace
+    dict(name='seg_city_r2', h=13, w=17, num_classes=19, timesteps=3, randsteps=2, bit_scale=0.01,
+         accumulation=False, noise_schedule='cosine', diffusion='ddim', seed=1, trace=True),
+    # 1-step plumbing case (BASELINE.json configs[0] shape class, scaled down)
+    dict(name='seg_ade_k1', h=32, w=32, num_classes=150, timesteps=1, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=2, trace=False),
+    # 10-step override (configs[2]) + accumulation + r=2
+    dict(name='seg_city_k10', h=12, w=20, num_classes=19, timesteps=10, randsteps=2, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=3, trace=False),
+    # linear schedule, larger bit scale, non-zero sample_range[0]
+    dict(name='seg_linear', h=9, w=33, num_classes=150, timesteps=4, randsteps=1, bit_scale=0.1,
+         accumulation=False, noise_schedule='linear', diffusion='ddim', seed=4, trace=False,
+         sample_range=(0.1, 0.999)),
+    # ancestral sampler (segmentors/ddp.py:248-290)
+    dict(name='seg_ddpm', h=10, w=14, num_classes=19, timesteps=4, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddpm', seed=5, trace=False),
+]
+
+DEPTH_CASES = [
+    dict(name='depth_k3_r2', h=11, w=19, timesteps=3, randsteps=2, bit_scale=0.1, seed=10,
+         min_depth=1e-3, max_depth=80.0),
+    dict(name='depth_k20', h=8, w=12, timesteps=20, randsteps=1, bit_scale=0.1, seed=11,
+         min_depth=1e-3, max_depth=80.0),
+]
+
+BEV_CASES = [
+    # fusion variant: 512 feature channels; scopes scaled so that x is 16x16 and the head runs at 25x25
+    dict(name='bev_fusion', h=16, w=16, feat_channels=512, timesteps=3, randsteps=2, bit_scale=0.01,
+         num_layers=5, seed=20, input_scope=[[-51.2, 51.2, 6.4], [-51.2, 51.2, 6.4]],
+         output_scope=[[-50, 50, 4.0], [-50, 50, 4.0]]),
+    # camera variant: 256 feature channels, rectangular
+    dict(name='bev_camera', h=12, w=20, feat_channels=256, timesteps=2, randsteps=1, bit_scale=0.01,
+         num_layers=5, seed=21, input_scope=[[-51.2, 51.2, 8.533333333333333], [-51.2, 51.2, 5.12]],
+         output_scope=[[-50, 50, 5.0], [-50, 50, 3.125]]),
+]
+
+
+def fingerprint(t):
+    t = t.double()
+    return [float(t.sum()), float(t.abs().sum())]
+
+
+class RandnPatch:
+    """Replace torch.randn / torch.randn_like inside the reference samplers by queued tensors."""
+
+    def __init__(self, start, per_step=None):
+        self.queue = [start]
+        self.per_step = list(per_step) if per_step is not None else []
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+
+        def randn(*a, **k):
+            t = self.queue.pop(0)
+            return t.clone()
+
+        def randn_like(x, *a, **k):
+            t = self.per_step.pop(0)
+            assert t.shape == x.shape
+            return t.clone()
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+def wrap_forward(module, sink):
+    """Record every result of ``module.forward`` (the reference calls head.forward_test ->
+    self.forward directly, which bypasses forward hooks)."""
+    orig = module.forward
+
+    def wrapped(*a, **k):
+        o = orig(*a, **k)
+        sink.append(o.clone())
+        return o
+
+    module.forward = wrapped
+
+
+def save(name, cfg, arrays):
+    path = os.path.join(HERE, name + '.npz')
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(path, config=np.array(json.dumps(cfg)), **arrays)
+    print(f'wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+def load_hot_path(model, sd):
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    missing_hot = [k for k in res.missing_keys
+                   if not k.startswith(('backbone.', 'neck.', 'auxiliary_head.'))]
+    assert not missing_hot, missing_hot
+
+
+def gen_seg():
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in SEG_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.timesteps = case['timesteps']
+        m.randsteps = case['randsteps']
+        m.bit_scale = case['bit_scale']
+        m.accumulation = case['accumulation']
+        m.noise_schedule = case['noise_schedule']
+        m.diffusion = case['diffusion']
+        if 'sample_range' in case:
+            m.sample_range = tuple(case['sample_range'])
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['seed'] + 100)
+        load_hot_path(model, sd)
+        x, noise = synthetic.make_inputs(1, case['h'], case['w'], case['randsteps'], 256, 256, seed=case['seed'])
+        step_noise = None
+        if case['diffusion'] == 'ddpm':
+            g = torch.Generator().manual_seed(case['seed'] + 7)
+            step_noise = torch.randn((case['timesteps'], case['randsteps'], 256, case['h'], case['w']), generator=g)
+
+        rec = dict(feat=[], logits=[], layer0=[], layer_last=[], mask_in=[])
+        def grab(key, sel=lambda i, o: o):
+            def hook(mod, i, o):
+                rec[key].append(sel(i, o).clone())      # returns None: never replaces the output
+            return hook
+
+        def grab_transform(mod, i, o):
+            rec['feat'].append(o.clone())
+            rec['mask_in'].append(i[0][:, 256:].clone())
+
+        wrap_forward(model.decode_head, rec['logits'])   # forward_test calls .forward directly
+        hooks = [
+            model.transform.register_forward_hook(grab_transform),
+            model.decode_head.encoder.layers[0].register_forward_hook(grab('layer0')),
+            model.decode_head.encoder.layers[-1].register_forward_hook(grab('layer_last')),
+        ]
+        with RandnPatch(noise[0], None if step_noise is None else list(step_noise)):
+            out = model.ddim_sample(x, None) if case['diffusion'] == 'ddim' else model.ddpm_sample(x, None)
+        for hk in hooks:
+            hk.remove()
+        arrays = dict(out=out, logits_last=rec['logits'][-1],
+                      x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd))
+        if case['trace']:
+            arrays['feat_step0'] = rec['feat'][0]
+            arrays['layer0_step0'] = rec['layer0'][0]            # (N, r, 256) seq-first as in the reference
+            arrays['layer_last_step0'] = rec['layer_last'][0]
+            arrays['logits_steps'] = torch.stack(rec['logits'])
+            arrays['mask_t_steps'] = torch.stack(rec['mask_in'][1:])   # noisy map entering steps 1..K-1
+        save(case['name'], dict(task='seg', **case), arrays)
+
+
+def gen_depth():
+    import ref_shim
+    build_depther, Config = ref_shim.import_depth()
+    from mmcv.cnn.utils import revert_sync_batchnorm
+    cfg_path = os.path.join(ref_shim.REF, 'depth/configs/ddp_kitti/ddp_swint_1k_w7_kitti_bs2x8_scale01.py')
+    for case in DEPTH_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.timesteps = case['timesteps']
+        m.randsteps = case['randsteps']
+        m.bit_scale = case['bit_scale']
+        m.min_depth = case['min_depth']
+        m.max_depth = case['max_depth']
+        model = revert_sync_batchnorm(build_depther(m)).eval()
+        assert hasattr(model.decode_head.encoder.layers[0], 'time_mlp'), 'time-aware layer not registered'
+        sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=case['seed'] + 100)
+        load_hot_path(model, sd)
+        x, noise = synthetic.make_inputs(1, case['h'], case['w'], case['randsteps'], 256, 1, seed=case['seed'])
+        rec = dict(pred=[], feat=[])
+        def grab(key):
+            def hook(mod, i, o):
+                rec[key].append(o.clone())
+            return hook
+
+        wrap_forward(model.decode_head, rec['pred'])
+        hooks = [model.down.register_forward_hook(grab('feat'))]
+        with RandnPatch(noise[0]):
+            out = model.sample(x, None)
+        for hk in hooks:
+            hk.remove()
+        save(case['name'], dict(task='depth', **case),
+             dict(out=out, depth_pred_steps=torch.stack(rec['pred']), feat_step0=rec['feat'][0],
+                  x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
+
+
+def gen_bev():
+    import ref_shim
+    ddp_mod, head_mod = ref_shim.import_bev()
+    from mmcv.utils import ConfigDict
+    for case in BEV_CASES:
+        nl = case['num_layers']
+        encoder = dict(
+            type='DetrTransformerEncoder', num_layers=nl,
+            transformerlayers=dict(
+                type='BaseTransformerLayer', use_time_mlp=True,
+                attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256, num_levels=1,
+                               num_heads=8, dropout=0.0),
+                ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, ffn_drop=0.,
+                              act_cfg=dict(type='GELU')),
+                operation_order=('self_attn', 'norm', 'ffn', 'norm')))
+        head = head_mod.DeformableHeadWithTime(
+            num_feature_levels=1, encoder=ConfigDict(encoder),
+            positional_encoding=ConfigDict(dict(type='SinePositionalEncoding', num_feats=128, normalize=True, offset=-0.5)),
+            classes=['a', 'b', 'c', 'd', 'e', 'f'], loss='focal',
+            grid_transform=dict(input_scope=case['input_scope'], output_scope=case['output_scope']),
+            in_channels=256).eval()
+        model = ddp_mod.DDP(bit_scale=case['bit_scale'], timesteps=case['timesteps'], randsteps=case['randsteps'],
+                            feat_channels=case['feat_channels']).eval()
+        sd = synthetic.make_state_dict('bev', 6, nl, case['feat_channels'], seed=case['seed'] + 100)
+        res = model.load_state_dict({k: v for k, v in sd.items() if not k.startswith('decode_head.')}, strict=False)
+        assert not res.unexpected_keys and not res.missing_keys, res
+        res = head.load_state_dict({k[len('decode_head.'):]: v for k, v in sd.items() if k.startswith('decode_head.')},
+                                   strict=False)
+        assert not res.unexpected_keys and not res.missing_keys, res
+        assert hasattr(head.encoder.layers[0], 'time_mlp') and head.encoder.layers[0].time_mlp is not None
+        x, noise = synthetic.make_inputs(1, case['h'], case['w'], case['randsteps'], case['feat_channels'], 256,
+                                         seed=case['seed'])
+        rec = dict(prob=[])
+        def grab_prob(mod, i, o):
+            rec['prob'].append(o.clone())
+
+        hk = head.register_forward_hook(grab_prob)
+        with RandnPatch(noise[0]):
+            out = model.ddim_sample([x], head)
+        hk.remove()
+        save(case['name'], dict(task='bev', **case),
+             dict(out=out, prob_steps=torch.stack(rec['prob']),
+                  x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'all'], default='all')
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    if args.task == 'all':
+        for t in ('seg', 'depth', 'bev'):       # separate processes: the trees' registries collide
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
+        return
+    with torch.no_grad():
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev}[args.task]()
+
+
+if __name__ == '__main__':
+    main()

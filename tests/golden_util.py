@@ -1,0 +1,51 @@
+"""Helpers shared by the oracle and HIP parity tests: load a golden fixture and regenerate its
+seeded inputs / weights (checking the stored fingerprints)."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from ddp_amd.utils import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def case_names(task=None):
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    if task is not None:
+        names = [n for n in names if n.startswith(task)]
+    return names
+
+
+def fingerprint(t):
+    t = t.double()
+    return [float(t.sum()), float(t.abs().sum())]
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if k != 'config'}
+    task = cfg['task']
+    nl = cfg.get('num_layers', 6)
+    cx = cfg.get('feat_channels', 256)
+    ncls = cfg.get('num_classes', 6 if task == 'bev' else 1)
+    sd = synthetic.make_state_dict(task, ncls, nl, cx, seed=cfg['seed'] + 100)
+    cm = 1 if task == 'depth' else 256
+    x, noise = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], cx, cm, seed=cfg['seed'])
+    # the seeded generators must reproduce exactly what the reference was fed
+    assert abs(synthetic.checksum(sd) - float(arrays['weights_fp'])) <= 1e-9 * abs(float(arrays['weights_fp']))
+    assert np.allclose(fingerprint(x), arrays['x_fp'].numpy(), rtol=1e-12)
+    assert np.allclose(fingerprint(noise), arrays['noise_fp'].numpy(), rtol=1e-12)
+    step_noise = None
+    if cfg.get('diffusion') == 'ddpm':
+        g = torch.Generator().manual_seed(cfg['seed'] + 7)
+        step_noise = torch.randn((cfg['timesteps'], cfg['randsteps'], 256, cfg['h'], cfg['w']), generator=g)
+    return cfg, sd, x, noise[0], step_noise, arrays
+
+
+def max_rel(a, b):
+    """max |a-b| / max |b|  (the parity metric of SURVEY.md §8d)."""
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))

@@ -1,0 +1,93 @@
+"""Pin the CPU oracle: known-answer values + every golden vector generated from the reference
+(tests/golden/gen_golden.py).  Runs on CPU."""
+import pytest
+import torch
+
+from oracle import ddp_oracle as O
+from golden_util import case_names, load_case, max_rel
+
+TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
+
+
+def test_schedule_known_answers():
+    # SURVEY.md §3.2 (values printed by the reference functions in the survey container)
+    t = torch.tensor([1.0, 2 / 3, 1 / 3, 0.0])
+    ls = O.alpha_cosine_log_snr(t)
+    ref = torch.tensor([-18.90747452, -1.09885418, 1.09776640, 11.51292515])
+    assert torch.allclose(ls, ref, rtol=0, atol=2e-6)
+    a, s = O.log_snr_to_alpha_sigma(ls)
+    assert torch.allclose(a, torch.tensor([7.8396e-05, 0.49995464, 0.86593378, 0.99999499]), atol=1e-6)
+    assert torch.allclose(s, torch.tensor([1.0, 0.86605161, 0.50015861, 0.00316226]), atol=1e-6)
+    lin = O.beta_linear_log_snr(t)
+    assert torch.allclose(lin, torch.tensor([-10.00005436, -4.43273306, -0.71198654, 9.21028996]), atol=2e-6)
+
+
+def test_time_pairs():
+    # segmentors/ddp.py:204-213 with time_difference=1
+    assert O.sampling_time_pairs(1) == [(1.0, 0.0)]
+    p = O.sampling_time_pairs(3)
+    assert [round(a, 6) for a, _ in p] == [1.0, round(2 / 3, 6), round(1 / 3, 6)]
+    assert [round(b, 6) for _, b in p] == [round(1 / 3, 6), 0.0, 0.0]
+
+
+def test_sine_posenc_known_answers():
+    # SURVEY.md §8 a9
+    pe = O.sine_positional_encoding(4, 6)
+    assert torch.allclose(pe[:4, 0, 0], torch.tensor([0.70710665, 0.70710689, 0.62889153, 0.77749306]), atol=1e-6)
+    assert torch.allclose(pe[128:132, 3, 5], torch.tensor([-0.5000006, 0.86602509, -0.96236897, 0.27174622]), atol=2e-6)
+
+
+@pytest.mark.parametrize('name', case_names('seg'))
+def test_seg_golden(name):
+    cfg, sd, x, noise, step_noise, g = load_case(name)
+    kw = dict(timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'],
+              sample_range0=cfg.get('sample_range', (0.0, 0.999))[0], noise_schedule=cfg['noise_schedule'],
+              accumulation=cfg['accumulation'])
+    if cfg['diffusion'] == 'ddpm':
+        out = O.ddpm_sample_seg(x, noise, step_noise, sd, **kw)
+    else:
+        trace = [] if cfg['trace'] else None
+        out = O.ddim_sample_seg(x, noise, sd, trace=trace, **kw)
+        if trace is not None:
+            assert max_rel(trace[0]['feat'], g['feat_step0']) < TOL
+            # reference layer outputs are seq-first (N, r, 256)
+            assert max_rel(trace[0]['layers'][0].transpose(0, 1), g['layer0_step0']) < TOL
+            assert max_rel(trace[0]['layers'][-1].transpose(0, 1), g['layer_last_step0']) < TOL
+            for s in range(cfg['timesteps']):
+                assert max_rel(trace[s]['logits'], g['logits_steps'][s]) < TOL
+            for s in range(cfg['timesteps'] - 1):
+                assert max_rel(trace[s]['mask_t'], g['mask_t_steps'][s]) < TOL
+    assert out.shape == g['out'].shape
+    assert max_rel(out, g['out']) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('seg_city_r2'))
+def test_seg_golden_explicit_taps(name):
+    """the explicit 4-corner pixel-unit gather (what the HIP kernel implements) == grid_sample."""
+    cfg, sd, x, noise, _, g = load_case(name)
+    out = O.ddim_sample_seg(x, noise, sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                            bit_scale=cfg['bit_scale'], accumulation=cfg['accumulation'], core='taps')
+    assert max_rel(out, g['out']) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('depth'))
+def test_depth_golden(name):
+    cfg, sd, x, noise, _, g = load_case(name)
+    trace = []
+    out = O.sample_depth(x, noise, sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                         bit_scale=cfg['bit_scale'], min_depth=cfg['min_depth'], max_depth=cfg['max_depth'],
+                         trace=trace)
+    assert max_rel(trace[0]['feat'], g['feat_step0']) < TOL
+    for s in range(cfg['timesteps']):
+        assert max_rel(trace[s]['depth_pred'], g['depth_pred_steps'][s]) < 5 * TOL, s
+    assert max_rel(out, g['out']) < 5 * TOL
+
+
+@pytest.mark.parametrize('name', case_names('bev'))
+def test_bev_golden(name):
+    cfg, sd, x, noise, _, g = load_case(name)
+    out = O.ddim_sample_bev(x, noise, sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                            bit_scale=cfg['bit_scale'], input_scope=cfg['input_scope'],
+                            output_scope=cfg['output_scope'])
+    assert out.shape == g['out'].shape
+    assert max_rel(out, g['out']) < TOL
