@@ -1,0 +1,104 @@
+"""ctypes binding of libddp_mi355x.so (include/ddp_mi355x.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the
+engine raises.  Build it with ``python -m ddp_amd.build`` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_LAYERS = 12
+MAX_STEPS = 64
+ABI_VERSION = 1
+
+TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
+SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
+
+_fp = C.c_void_p  # device pointers travel as raw addresses
+
+
+class DdpCfg(C.Structure):
+    _fields_ = [
+        ('abi_version', C.c_int32), ('task', C.c_int32), ('sampler', C.c_int32), ('batch', C.c_int32),
+        ('randsteps', C.c_int32), ('timesteps', C.c_int32), ('num_layers', C.c_int32),
+        ('num_classes', C.c_int32), ('feat_channels', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+        ('head_h', C.c_int32), ('head_w', C.c_int32), ('accumulation', C.c_int32),
+        ('bit_scale', C.c_float), ('min_depth', C.c_float), ('max_depth', C.c_float),
+        ('threshold', C.c_float),
+        ('bev_in_min', C.c_float * 2), ('bev_in_max', C.c_float * 2),
+        ('bev_out_first', C.c_float * 2), ('bev_out_step', C.c_float * 2),
+    ]
+
+
+LAYER_FIELDS = ['sampling_offsets_w', 'sampling_offsets_b', 'attention_weights_w', 'attention_weights_b',
+                'value_proj_w', 'value_proj_b', 'output_proj_w', 'output_proj_b', 'ffn0_w', 'ffn0_b',
+                'ffn1_w', 'ffn1_b', 'norm0_w', 'norm0_b', 'norm1_w', 'norm1_b', 'time_w', 'time_b']
+
+
+class DdpLayerWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in LAYER_FIELDS]
+
+
+TOP_FIELDS = ['transform_w', 'transform_b', 'time_freq', 'time1_w', 'time1_b', 'time3_w', 'time3_b',
+              'embedding', 'head_w', 'head_b']
+
+
+class DdpWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in TOP_FIELDS] + [('layers', DdpLayerWeights * MAX_LAYERS)]
+
+
+class DdpStep(C.Structure):
+    _fields_ = [('time_in', C.c_float), ('alpha', C.c_float), ('sigma', C.c_float),
+                ('alpha_next', C.c_float), ('sigma_next', C.c_float), ('ddpm_c', C.c_float),
+                ('ddpm_std', C.c_float), ('ddpm_add_noise', C.c_int32)]
+
+
+EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
+           'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_time_embed', 'ddp_ddim_update_seg']
+
+_lib = None
+
+
+class DdpError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) and return the shared library; raises if it is missing - there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise DdpError(f'{path} not found: build it with `python -m ddp_amd.build` '
+                       '(hipcc --offload-arch=gfx950); ddp_amd has no non-HIP fallback')
+    lib = C.CDLL(path)
+    lib.ddp_last_error.restype = C.c_char_p
+    lib.ddp_abi_version.restype = C.c_int
+    lib.ddp_query_workspace.argtypes = [C.POINTER(DdpCfg), C.POINTER(C.c_size_t)]
+    lib.ddp_prepare.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp]
+    lib.ddp_sample.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp, _fp, _fp,
+                               _fp, _fp]
+    lib.ddp_head_forward.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), _fp, _fp, _fp, _fp, _fp]
+    lib.ddp_msda_forward.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]
+    lib.ddp_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+    lib.ddp_time_embed.argtypes = [C.POINTER(DdpWeights), C.c_int, C.POINTER(C.c_float), C.c_int, _fp, _fp, _fp, _fp]
+    lib.ddp_ddim_update_seg.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.POINTER(DdpStep), _fp]
+    for n in EXPORTS:
+        if n not in ('ddp_last_error',):
+            getattr(lib, n).restype = C.c_int if n != 'ddp_last_error' else C.c_char_p
+    lib.ddp_last_error.restype = C.c_char_p
+    if lib.ddp_abi_version() != ABI_VERSION:
+        raise DdpError(f'ABI mismatch: library {lib.ddp_abi_version()} vs binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DdpError(f'libddp_mi355x error {rc}: {load().ddp_last_error().decode()}')

@@ -1,0 +1,563 @@
+// ddp_api.hip - C-ABI entry points of libddp_mi355x.so and the K-step loop orchestration.
+//
+// One stream, no host synchronisation, no allocation: the caller hands over a workspace which is
+// carved deterministically from `ddp_cfg` (constants first, then activations).  Layout in HBM:
+// every activation is token-major fp32 (rows = tokens of all B*r maps back to back, 256 channels).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ddp_internal.h"
+
+namespace ddp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DDP_E_LAUNCH;
+  }
+  return DDP_OK;
+}
+
+#define DDP_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != DDP_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+inline size_t align64(size_t floats) { return (floats + 63) & ~size_t(63); }  // 256-byte granules
+
+struct Carve {
+  float* base;
+  size_t off = 0;
+  float* take(size_t floats) {
+    float* p = base ? base + off : nullptr;
+    off += align64(floats);
+    return p;
+  }
+};
+
+struct Layout {
+  // dims
+  int B, r, K, L, Kc, Cx, Cm, h, w, hh, wh, N, Nh, R;
+  size_t M0, M;   // tokens at (h,w) and at the head grid, over all B*r maps
+  int ldl;        // row stride of logits / prob buffers
+  // constants
+  float *tin, *u, *hid, *temb, *film, *lut, *wx, *wm, *wtap;
+  float *wcat[DDP_MAX_LAYERS], *bcat[DDP_MAX_LAYERS], *py[DDP_MAX_LAYERS], *px[DDP_MAX_LAYERS];
+  // activations
+  float *xproj, *mask, *pred, *feat0, *q, *q1, *v, *s, *samp, *hbuf, *logits, *prob, *snoise, *xtok;
+  size_t total;
+};
+
+int validate(const ddp_cfg* c) {
+  if (!c) {
+    set_error("cfg is NULL");
+    return DDP_E_NULL;
+  }
+  if (c->abi_version != DDP_ABI_VERSION) {
+    set_error("abi_version %d != %d", c->abi_version, DDP_ABI_VERSION);
+    return DDP_E_BADCFG;
+  }
+  if (c->task < 0 || c->task > 2) {
+    set_error("unknown task %d", c->task);
+    return DDP_E_BADCFG;
+  }
+  if (c->batch < 1 || c->randsteps < 1 || c->timesteps < 1 || c->timesteps > DDP_MAX_STEPS) {
+    set_error("batch/randsteps/timesteps out of range (%d,%d,%d)", c->batch, c->randsteps, c->timesteps);
+    return DDP_E_BADCFG;
+  }
+  if (c->num_layers < 1 || c->num_layers > DDP_MAX_LAYERS) {
+    set_error("num_layers %d out of range", c->num_layers);
+    return DDP_E_BADCFG;
+  }
+  if (c->h < 1 || c->w < 1 || c->head_h < 1 || c->head_w < 1) {
+    set_error("bad spatial size");
+    return DDP_E_BADCFG;
+  }
+  if (c->task != DDP_TASK_BEV && (c->head_h != c->h || c->head_w != c->w)) {
+    set_error("head grid must equal (h,w) except for bev");
+    return DDP_E_BADCFG;
+  }
+  if (c->feat_channels < 32 || c->feat_channels % 32) {
+    set_error("feat_channels %d must be a positive multiple of 32", c->feat_channels);
+    return DDP_E_BADCFG;
+  }
+  if (c->task != DDP_TASK_DEPTH && (c->num_classes < 1 || c->num_classes > 256)) {
+    set_error("num_classes %d out of range [1,256]", c->num_classes);
+    return DDP_E_BADCFG;
+  }
+  if (c->task == DDP_TASK_BEV && c->num_classes > 32) {
+    set_error("bev supports at most 32 classes");
+    return DDP_E_BADCFG;
+  }
+  if (c->sampler != DDP_SAMPLER_DDIM && !(c->sampler == DDP_SAMPLER_DDPM && c->task == DDP_TASK_SEG)) {
+    set_error("sampler %d unsupported for task %d (the reference defines ddpm for seg only)", c->sampler, c->task);
+    return DDP_E_BADCFG;
+  }
+  const double tokens = double(c->batch) * c->randsteps * double(c->head_h) * c->head_w;
+  if (tokens > 1.5e9 / 1024) {  // keep int row*1024 offsets and 32-bit row counters safe
+    set_error("problem too large for one call: %.0f tokens", tokens);
+    return DDP_E_BADCFG;
+  }
+  return DDP_OK;
+}
+
+void carve(const ddp_cfg* c, float* base, Layout* o) {
+  Carve cv{base};
+  o->B = c->batch;
+  o->r = c->randsteps;
+  o->K = c->timesteps;
+  o->L = c->num_layers;
+  o->Kc = c->task == DDP_TASK_DEPTH ? 1 : c->num_classes;
+  o->Cx = c->feat_channels;
+  o->Cm = c->task == DDP_TASK_DEPTH ? 1 : 256;
+  o->h = c->h;
+  o->w = c->w;
+  o->hh = c->head_h;
+  o->wh = c->head_w;
+  o->N = c->h * c->w;
+  o->Nh = c->head_h * c->head_w;
+  o->R = c->batch * c->randsteps;
+  o->M0 = size_t(o->R) * o->N;
+  o->M = size_t(o->R) * o->Nh;
+  o->ldl = c->task == DDP_TASK_SEG ? ((o->Kc + 31) / 32) * 32 : 32;
+  // constants
+  o->tin = cv.take(DDP_MAX_STEPS);
+  o->u = cv.take(size_t(o->K) * DDP_SINU_FEATS);
+  o->hid = cv.take(size_t(o->K) * DDP_TIME_DIM);
+  o->temb = cv.take(size_t(o->K) * DDP_TIME_DIM);
+  o->film = cv.take(size_t(o->K) * o->L * 512);
+  o->lut = cv.take(size_t(o->Kc + 1) * 256);
+  o->wx = cv.take(size_t(256) * o->Cx);
+  o->wm = cv.take(size_t(256) * o->Cm);
+  o->wtap = cv.take(size_t(9) * 256);
+  for (int l = 0; l < DDP_MAX_LAYERS; ++l) {
+    const bool on = l < o->L;
+    o->wcat[l] = on ? cv.take(96 * 256) : nullptr;
+    o->bcat[l] = on ? cv.take(96) : nullptr;
+    o->py[l] = on ? cv.take(size_t(o->hh) * 96) : nullptr;
+    o->px[l] = on ? cv.take(size_t(o->wh) * 96) : nullptr;
+  }
+  // activations
+  o->xproj = cv.take(size_t(o->B) * o->N * 256);
+  o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
+  o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
+  o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
+  o->q = cv.take(o->M * 256);
+  o->q1 = cv.take(o->M * 256);
+  o->v = cv.take(o->M * 256);
+  o->s = cv.take(o->M * 256);
+  o->samp = cv.take(o->M * DDP_SAMP_STRIDE);
+  size_t hb = o->M * DDP_FFN;
+  const size_t xt = size_t(o->B) * o->N * o->Cx;
+  if (xt > hb) hb = xt;
+  o->hbuf = cv.take(hb);
+  o->xtok = o->hbuf;  // x in token-major form is dead once xproj exists
+  o->logits = cv.take(o->M * o->ldl);
+  o->prob = cv.take(o->M * o->ldl);
+  o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
+  o->total = cv.off * sizeof(float);
+}
+
+BevGeom bev_geom(const ddp_cfg* c) {
+  BevGeom g;
+  g.h = c->h;
+  g.w = c->w;
+  g.hh = c->head_h;
+  g.wh = c->head_w;
+  for (int a = 0; a < 2; ++a) {
+    g.in_min[a] = c->bev_in_min[a];
+    g.in_max[a] = c->bev_in_max[a];
+    g.out_first[a] = c->bev_out_first[a];
+    g.out_step[a] = c->bev_out_step[a];
+  }
+  return g;
+}
+
+int check_ptr(const void* p, const char* name) {
+  if (!p) {
+    set_error("%s is NULL", name);
+    return DDP_E_NULL;
+  }
+  if (reinterpret_cast<uintptr_t>(p) & 15) {
+    set_error("%s is not 16-byte aligned", name);
+    return DDP_E_ALIGN;
+  }
+  return DDP_OK;
+}
+
+int check_weights(const ddp_cfg* c, const ddp_weights* w) {
+  if (!w) {
+    set_error("weights is NULL");
+    return DDP_E_NULL;
+  }
+  DDP_TRY(check_ptr(w->transform_w, "transform_w"));
+  DDP_TRY(check_ptr(w->transform_b, "transform_b"));
+  DDP_TRY(check_ptr(w->head_w, "head_w"));
+  DDP_TRY(check_ptr(w->head_b, "head_b"));
+  if (c->task != DDP_TASK_DEPTH) DDP_TRY(check_ptr(w->embedding, "embedding"));
+  for (int l = 0; l < c->num_layers; ++l) {
+    const ddp_layer_weights& lw = w->layers[l];
+    const void* ps[] = {lw.sampling_offsets_w, lw.sampling_offsets_b, lw.attention_weights_w, lw.attention_weights_b,
+                        lw.value_proj_w, lw.value_proj_b, lw.output_proj_w, lw.output_proj_b, lw.ffn0_w, lw.ffn0_b,
+                        lw.ffn1_w, lw.ffn1_b, lw.norm0_w, lw.norm0_b, lw.norm1_w, lw.norm1_b};
+    for (const void* p : ps) DDP_TRY(check_ptr(p, "layer weight"));
+  }
+  return DDP_OK;
+}
+
+// time embedding + FiLM for S time inputs already on device at tin (segmentors/ddp.py:107-112,
+// utils/transformer.py:275-278)
+int time_embed_dev(const ddp_weights* w, int L, const float* tin, int S, float* u, float* hid, float* temb,
+                   float* film, hipStream_t st) {
+  DDP_TRY(launch_sinusoid(w->time_freq, tin, S, u, st));
+  DDP_TRY(launch_matvec(w->time1_w, w->time1_b, u, hid, DDP_SINU_FEATS, DDP_TIME_DIM, S, DDP_SINU_FEATS,
+                        DDP_TIME_DIM, 0, 1, st));
+  DDP_TRY(launch_matvec(w->time3_w, w->time3_b, hid, temb, DDP_TIME_DIM, DDP_TIME_DIM, S, DDP_TIME_DIM,
+                        DDP_TIME_DIM, 0, 0, st));
+  for (int l = 0; l < L; ++l) {
+    if (!w->layers[l].time_w) continue;
+    DDP_TRY(launch_matvec(w->layers[l].time_w, w->layers[l].time_b, temb, film + size_t(l) * 512, DDP_TIME_DIM, 512,
+                          S, DDP_TIME_DIM, L * 512, 2, 0, st));
+  }
+  return DDP_OK;
+}
+
+// constants that do not depend on the schedule
+int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipStream_t st) {
+  DDP_TRY(launch_pack_cols(w->transform_w, o.Cx + o.Cm, 0, 256, o.Cx, o.wx, st));
+  DDP_TRY(launch_pack_cols(w->transform_w, o.Cx + o.Cm, o.Cx, 256, o.Cm, o.wm, st));
+  if (c->task == DDP_TASK_SEG) DDP_TRY(launch_build_lut(w->embedding, o.lut, o.Kc + 1, c->bit_scale, st));
+  if (c->task == DDP_TASK_DEPTH) DDP_TRY(launch_pack_conv3x3(w->head_w, o.wtap, st));
+  for (int l = 0; l < o.L; ++l) {
+    const ddp_layer_weights& lw = w->layers[l];
+    DDP_TRY(launch_pack_rows(lw.sampling_offsets_w, 64, lw.attention_weights_w, 32, o.wcat[l], 256, st));
+    DDP_TRY(launch_pack_rows(lw.sampling_offsets_b, 64, lw.attention_weights_b, 32, o.bcat[l], 1, st));
+    DDP_TRY(launch_pos_tables(o.wcat[l], o.bcat[l], o.py[l], o.px[l], o.hh, o.wh, st));
+  }
+  return DDP_OK;
+}
+
+// DetrTransformerEncoder over token-major q (in/out), FiLM vectors film (L,512) or nullptr
+int encoder_forward(const ddp_weights* w, const Layout& o, const float* film, hipStream_t st) {
+  const int M = int(o.M);
+  for (int l = 0; l < o.L; ++l) {
+    const ddp_layer_weights& lw = w->layers[l];
+    // value / sampling projections (multi_scale_deform_attn.py:313-328)
+    DDP_TRY(launch_linear(o.q, 256, lw.value_proj_w, 256, lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, 0, st));
+    DDP_TRY(launch_linear_samp(o.q, 256, o.wcat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
+    // bilinear gather + weighted sum (:94-151)
+    DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
+    // output_proj + identity, LayerNorm (:352-358; utils/transformer.py:390-392)
+    DDP_TRY(launch_linear_res_ln(o.s, 256, lw.output_proj_w, 256, lw.output_proj_b, o.q, 256, lw.norm0_w, lw.norm0_b,
+                                 nullptr, o.q1, 256, M, 256, st));
+    // FFN + identity, LayerNorm, FiLM (mmcv FFN :269-280; utils/transformer.py:413-417)
+    DDP_TRY(launch_linear(o.q1, 256, lw.ffn0_w, 256, lw.ffn0_b, nullptr, 0, 0, 0, o.hbuf, DDP_FFN, M, DDP_FFN, 256, 1, st));
+    const float* fl = (film && lw.time_w) ? film + size_t(l) * 512 : nullptr;
+    DDP_TRY(launch_linear_res_ln(o.hbuf, DDP_FFN, lw.ffn1_w, DDP_FFN, lw.ffn1_b, o.q1, 256, lw.norm1_w, lw.norm1_b, fl,
+                                 o.q, 256, M, DDP_FFN, st));
+  }
+  return DDP_OK;
+}
+
+}  // namespace
+}  // namespace ddp
+
+using namespace ddp;
+
+extern "C" {
+
+const char* ddp_last_error(void) { return g_err; }
+int ddp_abi_version(void) { return DDP_ABI_VERSION; }
+
+int ddp_query_workspace(const ddp_cfg* cfg, size_t* bytes) {
+  DDP_TRY(validate(cfg));
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  Layout o;
+  carve(cfg, nullptr, &o);
+  *bytes = o.total;
+  return DDP_OK;
+}
+
+int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps, void* d_workspace,
+                void* stream) {
+  DDP_TRY(validate(cfg));
+  DDP_TRY(check_weights(cfg, weights));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  if (!steps) {
+    set_error("steps is NULL");
+    return DDP_E_NULL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Layout o;
+  carve(cfg, static_cast<float*>(d_workspace), &o);
+  DDP_TRY(prepare_static(cfg, weights, o, st));
+  float tin[DDP_MAX_STEPS];
+  for (int s = 0; s < o.K; ++s) tin[s] = steps[s].time_in;
+  DDP_TRY(launch_write_floats(tin, o.K, o.tin, st));
+  DDP_TRY(time_embed_dev(weights, o.L, o.tin, o.K, o.u, o.hid, o.temb, o.film, st));
+  return DDP_OK;
+}
+
+int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps, const float* d_x,
+               const float* d_noise, const float* d_step_noise, float* d_out, void* d_workspace, void* stream) {
+  DDP_TRY(validate(cfg));
+  DDP_TRY(check_weights(cfg, weights));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  DDP_TRY(check_ptr(d_x, "x"));
+  DDP_TRY(check_ptr(d_noise, "noise"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (!steps) {
+    set_error("steps is NULL");
+    return DDP_E_NULL;
+  }
+  if (cfg->sampler == DDP_SAMPLER_DDPM) DDP_TRY(check_ptr(d_step_noise, "step_noise"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Layout o;
+  carve(cfg, static_cast<float*>(d_workspace), &o);
+  const int M = int(o.M), M0 = int(o.M0);
+  const BevGeom geom = bev_geom(cfg);
+
+  // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
+  DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
+  DDP_TRY(launch_linear(o.xtok, o.Cx, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256,
+                        o.Cx, 0, st));
+  if (cfg->task == DDP_TASK_DEPTH) {
+    if (hipMemcpyAsync(o.mask, d_noise, size_t(M0) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      set_error("noise copy failed");
+      return DDP_E_LAUNCH;
+    }
+  } else {
+    DDP_TRY(launch_nchw_to_tok(d_noise, o.mask, o.R, 256, o.N, st));
+  }
+
+  for (int s = 0; s < o.K; ++s) {
+    const ddp_step& sp = steps[s];
+    const float* film = o.film + size_t(s) * o.L * 512;
+    // feat = transform(cat[x, mask_t])
+    if (cfg->task == DDP_TASK_DEPTH) {
+      DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.q, o.B, o.r, o.N, st));
+    } else {
+      float* dst = cfg->task == DDP_TASK_BEV ? o.feat0 : o.q;
+      DDP_TRY(launch_linear(o.mask, 256, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, dst, 256, M0, 256, 256, 0, st));
+      if (cfg->task == DDP_TASK_BEV) DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, geom, st));
+    }
+    DDP_TRY(encoder_forward(weights, o, film, st));
+    if (cfg->task == DDP_TASK_SEG) {
+      DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
+                            256, 0, st));
+      SegUpdateArgs a;
+      a.logits = o.logits;
+      a.ldl = o.ldl;
+      a.num_classes = o.Kc;
+      a.lut = o.lut;
+      a.mask = o.mask;
+      a.prob = o.prob;
+      a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
+      a.step_noise = nullptr;
+      a.sampler = cfg->sampler;
+      a.st = sp;
+      a.rows = M;
+      if (cfg->sampler == DDP_SAMPLER_DDPM && sp.ddpm_add_noise) {
+        DDP_TRY(launch_nchw_to_tok(d_step_noise + size_t(s) * M0 * 256, o.snoise, o.R, 256, o.N, st));
+        a.step_noise = o.snoise;
+      }
+      DDP_TRY(launch_seg_update(a, st));
+    } else if (cfg->task == DDP_TASK_DEPTH) {
+      DDP_TRY(launch_linear(o.q, 256, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st));
+      DepthUpdateArgs a;
+      a.taps = o.logits;
+      a.bias = 0.f;
+      a.bias_ptr = weights->head_b;
+      a.depth_t = o.mask;
+      a.pred = o.pred;
+      a.B_r = o.R;
+      a.h = o.h;
+      a.w = o.w;
+      a.min_depth = cfg->min_depth;
+      a.max_depth = cfg->max_depth;
+      a.bit_scale = cfg->bit_scale;
+      a.eps_depth = cfg->min_depth;
+      a.st = sp;
+      DDP_TRY(launch_depth_update(a, st));
+    } else {
+      DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256,
+                            0, st));
+      BevUpdateArgs a;
+      a.logits = o.logits;
+      a.num_classes = o.Kc;
+      a.emb = weights->embedding;
+      a.mask = o.mask;
+      a.prob = o.prob;
+      a.first = (s == 0);
+      a.R = o.R;
+      a.g = geom;
+      a.threshold = cfg->threshold;
+      a.bit_scale = cfg->bit_scale;
+      a.st = sp;
+      DDP_TRY(launch_bev_update(a, st));
+    }
+  }
+  // reduction over (steps x r) and token-major -> NCHW (ddp.py:243-245)
+  if (cfg->task == DDP_TASK_SEG) {
+    if (cfg->accumulation)
+      DDP_TRY(launch_finalize_nchw(o.prob, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r * o.K), st));
+    else
+      DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r), st));
+  } else if (cfg->task == DDP_TASK_DEPTH) {
+    DDP_TRY(launch_mean_r(o.pred, d_out, o.B, o.r, o.N, st));
+  } else {
+    DDP_TRY(launch_finalize_nchw(o.prob, 32, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r * o.K), st));
+  }
+  return DDP_OK;
+}
+
+int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float* d_feat, const float* d_temb,
+                     float* d_out, void* d_workspace, void* stream) {
+  DDP_TRY(validate(cfg));
+  DDP_TRY(check_weights(cfg, weights));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  DDP_TRY(check_ptr(d_feat, "feat"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Layout o;
+  carve(cfg, static_cast<float*>(d_workspace), &o);
+  const int M = int(o.M);
+  DDP_TRY(prepare_static(cfg, weights, o, st));
+  const float* film = nullptr;
+  if (d_temb) {
+    for (int l = 0; l < o.L; ++l) {
+      if (!weights->layers[l].time_w) continue;
+      DDP_TRY(launch_matvec(weights->layers[l].time_w, weights->layers[l].time_b, d_temb, o.film + size_t(l) * 512,
+                            DDP_TIME_DIM, 512, 1, DDP_TIME_DIM, o.L * 512, 2, 0, st));
+    }
+    film = o.film;
+  }
+  if (cfg->task == DDP_TASK_BEV) {
+    DDP_TRY(launch_nchw_to_tok(d_feat, o.feat0, o.R, 256, o.N, st));
+    DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, bev_geom(cfg), st));
+  } else {
+    DDP_TRY(launch_nchw_to_tok(d_feat, o.q, o.R, 256, o.N, st));
+  }
+  DDP_TRY(encoder_forward(weights, o, film, st));
+  if (cfg->task == DDP_TASK_SEG) {
+    DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256,
+                          0, st));
+    DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.R, 1, o.Nh, o.Kc, 1.0f, st));
+  } else if (cfg->task == DDP_TASK_DEPTH) {
+    DDP_TRY(launch_linear(o.q, 256, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st));
+    DepthUpdateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.taps = o.logits;
+    a.bias_ptr = weights->head_b;
+    a.depth_t = nullptr;
+    a.pred = d_out;  // (R,1,h,w) == (R*N)
+    a.B_r = o.R;
+    a.h = o.h;
+    a.w = o.w;
+    a.min_depth = cfg->min_depth;
+    a.max_depth = cfg->max_depth;
+    a.bit_scale = cfg->bit_scale;
+    a.eps_depth = cfg->min_depth;
+    DDP_TRY(launch_depth_update(a, st));
+  } else {
+    DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256, 0,
+                          st));
+    BevUpdateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.logits = o.logits;
+    a.num_classes = o.Kc;
+    a.emb = weights->embedding;
+    a.mask = nullptr;
+    a.prob = o.prob;
+    a.first = 1;
+    a.R = o.R;
+    a.g = bev_geom(cfg);
+    a.threshold = cfg->threshold;
+    a.bit_scale = cfg->bit_scale;
+    DDP_TRY(launch_bev_update(a, st));
+    DDP_TRY(launch_finalize_nchw(o.prob, 32, d_out, o.R, 1, o.Nh, o.Kc, 1.0f, st));
+  }
+  return DDP_OK;
+}
+
+int ddp_msda_forward(const float* d_value, const float* d_samp, float* d_out, int rows, int h, int w, void* stream) {
+  DDP_TRY(check_ptr(d_value, "value"));
+  DDP_TRY(check_ptr(d_samp, "samp"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (rows < 0 || h < 1 || w < 1 || rows % (h * w)) {
+    set_error("msda: rows=%d must be a multiple of h*w=%d", rows, h * w);
+    return DDP_E_BADCFG;
+  }
+  return launch_msda_gather(d_value, d_samp, d_out, rows, h * w, h, w, static_cast<hipStream_t>(stream));
+}
+
+int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k, int gelu,
+               void* stream) {
+  DDP_TRY(check_ptr(d_a, "a"));
+  DDP_TRY(check_ptr(d_w, "w"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (n % 4) {
+    set_error("linear: n=%d must be a multiple of 4 (row stride of out)", n);
+    return DDP_E_BADCFG;
+  }
+  return launch_linear(d_a, k, d_w, k, d_bias, nullptr, 0, 0, 0, d_out, n, m, n, k, gelu, static_cast<hipStream_t>(stream));
+}
+
+int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time_in_host, int s, float* d_temb,
+                   float* d_film, float* d_scratch, void* stream) {
+  if (!weights || !time_in_host || s < 1 || s > DDP_MAX_STEPS || num_layers < 0 || num_layers > DDP_MAX_LAYERS) {
+    set_error("time_embed: bad arguments");
+    return DDP_E_BADCFG;
+  }
+  DDP_TRY(check_ptr(d_temb, "temb"));
+  DDP_TRY(check_ptr(d_scratch, "scratch"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* tin = d_scratch;
+  float* u = d_scratch + 64;
+  float* hid = u + align64(size_t(s) * DDP_SINU_FEATS);
+  DDP_TRY(launch_write_floats(time_in_host, s, tin, st));
+  return time_embed_dev(weights, d_film ? num_layers : 0, tin, s, u, hid, d_temb, d_film, st);
+}
+
+int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, const float* d_lut, float* d_mask,
+                        int rows, const ddp_step* step, void* stream) {
+  DDP_TRY(check_ptr(d_logits, "logits"));
+  DDP_TRY(check_ptr(d_lut, "lut"));
+  DDP_TRY(check_ptr(d_mask, "mask"));
+  if (!step || num_classes < 1 || num_classes > 256) {
+    set_error("ddim_update_seg: bad arguments");
+    return DDP_E_BADCFG;
+  }
+  SegUpdateArgs a;
+  a.logits = d_logits;
+  a.ldl = ld_logits;
+  a.num_classes = num_classes;
+  a.lut = d_lut;
+  a.mask = d_mask;
+  a.prob = nullptr;
+  a.prob_mode = 0;
+  a.step_noise = nullptr;
+  a.sampler = DDP_SAMPLER_DDIM;
+  a.st = *step;
+  a.rows = rows;
+  return launch_seg_update(a, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// ddp_gemm.hip - instantiations / launchers of the fp32-MFMA token GEMM (gemm_f32.h).
+#include "ddp_internal.h"
+#include "gemm_f32.h"
+
+namespace ddp {
+
+namespace {
+
+template <int NT, class Epi>
+int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const Epi& epi,
+                hipStream_t st) {
+  if (M <= 0) return DDP_OK;
+  if (K % GEMM_BK != 0 || (lda & 3) || (ldw & 3)) {
+    set_error("gemm: K=%d must be a multiple of %d and lda/ldw multiples of 4", K, GEMM_BK);
+    return DDP_E_BADCFG;
+  }
+  const int n_tiles_n = (N + NT * 32 - 1) / (NT * 32);
+  const size_t lds = gemm_lds_bytes<NT>();
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, Epi>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_gemm_tok<NT, Epi>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS), lds, st, A, lda,
+                     W, ldw, M, N, K, n_tiles_n, epi);
+  return check_launch("k_gemm_tok");
+}
+
+}  // namespace
+
+int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
+                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
+                  hipStream_t st) {
+  EpiBias e;
+  e.bias = bias;
+  e.add = add;
+  e.ld_add = ld_add;
+  e.rn = rn;
+  e.n_tok = n_tok;
+  e.out = out;
+  e.ldo = ldo;
+  e.n_valid = N;
+  e.gelu = gelu;
+  if (ldo & 3) {
+    set_error("linear: N=%d, ldo=%d must be a multiple of 4", N, ldo);
+    return DDP_E_BADCFG;
+  }
+  if (N <= 32) return launch_gemm<1>(A, lda, W, ldw, M, N, K, e, st);
+  if (N <= 96) return launch_gemm<3>(A, lda, W, ldw, M, N, K, e, st);
+  if (N <= 160) return launch_gemm<5>(A, lda, W, ldw, M, N, K, e, st);
+  return launch_gemm<8>(A, lda, W, ldw, M, N, K, e, st);
+}
+
+int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
+                         const float* res, int ldres, const float* gamma, const float* beta,
+                         const float* film, float* out, int ldo, int M, int K, hipStream_t st) {
+  EpiResLN e;
+  e.bias = bias;
+  e.res = res;
+  e.ldres = ldres;
+  e.gamma = gamma;
+  e.beta = beta;
+  e.film = film;
+  e.out = out;
+  e.ldo = ldo;
+  return launch_gemm<8>(A, lda, W, ldw, M, 256, K, e, st);
+}
+
+int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
+                       int n_tok, int w, float* out, int M, hipStream_t st) {
+  EpiSamp e;
+  e.py = py;
+  e.px = px;
+  e.n_tok = n_tok;
+  e.w = w;
+  e.out = out;
+  return launch_gemm<3>(A, lda, Wcat, 256, M, 96, 256, e, st);
+}
+
+}  // namespace ddp

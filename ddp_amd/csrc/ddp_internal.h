@@ -1,0 +1,92 @@
+// ddp_internal.h - internal launch interface between the translation units of libddp_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/ddp_mi355x.h"
+
+namespace ddp {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- ddp_gemm.hip -------------------------------------------------------------------------------
+// out = A W^T + bias (+ add[row map]) (+GELU);  A (M,K) lda, W (N,K) ldw; K % 32 == 0, N <= any.
+int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
+                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
+                  hipStream_t st);
+// out = LN(A W^T + bias + res) * gamma + beta [ * (scale+1) + shift ];  N == 256
+int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
+                         const float* res, int ldres, const float* gamma, const float* beta,
+                         const float* film, float* out, int ldo, int M, int K, hipStream_t st);
+// samp = epilogue(A Wcat^T) with positional tables; Wcat (96,256)
+int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
+                       int n_tok, int w, float* out, int M, hipStream_t st);
+
+// ---- ddp_kernels.hip ----------------------------------------------------------------------------
+int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st);
+int launch_msda_gather(const float* value, const float* samp, float* out, int rows, int n_tok, int h, int w,
+                       hipStream_t st);
+int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);
+// y[s][o] = out_act( W[o][:] . in_act(x[s][:]) + b[o] )   act: 0 none, 1 gelu(out), 2 silu(in)
+int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,
+                  int ldx, int ldy, int in_act, int out_act, hipStream_t st);
+int launch_build_lut(const float* emb, float* lut, int rows, float bit_scale, hipStream_t st);
+int launch_pos_tables(const float* wcat /* (96,256) */, const float* bcat /* (96) */, float* py, float* px,
+                      int h, int w, hipStream_t st);
+int launch_pack_cols(const float* in, int ld_in, int off, int rows, int cols, float* out, hipStream_t st);
+int launch_pack_conv3x3(const float* w, float* out, hipStream_t st);
+int launch_write_floats(const float* host_vals, int n, float* out, hipStream_t st);
+int launch_pack_rows(const float* a, int rows_a, const float* b, int rows_b, float* out, int cols, hipStream_t st);
+// seg x0 projection + ddim/ddpm update + accumulation (segmentors/ddp.py:235-245,276-287)
+struct SegUpdateArgs {
+  const float* logits;  // (M, ldl)
+  int ldl, num_classes;
+  const float* lut;     // (K+1, 256)
+  float* mask;          // (M, 256) in/out
+  float* prob;          // (M, ldl) accumulated softmax / last logits; may be nullptr
+  int prob_mode;        // 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = logits
+  const float* step_noise;  // ddpm (M,256) token-major or nullptr
+  int sampler;
+  ddp_step st;
+  int rows;
+};
+int launch_seg_update(const SegUpdateArgs& a, hipStream_t st);
+// out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]
+int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
+                         hipStream_t st);
+// depth
+int launch_feat_depth(const float* xproj, const float* wm, const float* d, float* q, int B, int r, int N,
+                      hipStream_t st);
+struct DepthUpdateArgs {
+  const float* taps;   // (M, 32) 9 per-tap partial dots of conv_depth
+  float bias;
+  const float* bias_ptr;
+  float* depth_t;      // (M) in/out noisy depth
+  float* pred;         // (M) metric depth prediction out
+  int B_r, h, w;
+  float min_depth, max_depth, bit_scale, eps_depth;
+  ddp_step st;
+};
+int launch_depth_update(const DepthUpdateArgs& a, hipStream_t st);
+int launch_mean_r(const float* pred, float* out, int B, int r, int N, hipStream_t st);
+// bev
+struct BevGeom {
+  int h, w, hh, wh;
+  float in_min[2], in_max[2], out_first[2], out_step[2];
+};
+int launch_bev_resample(const float* feat, float* out, int R, const BevGeom& g, hipStream_t st);
+struct BevUpdateArgs {
+  const float* logits;  // (R*Nh, 32) raw conv_seg
+  int num_classes;
+  const float* emb;     // (K+1, 256) raw embedding table
+  float* mask;          // (R*N, 256)
+  float* prob;          // (R*Nh, 32) accumulated sigmoid
+  int first;            // prob = (first) else +=
+  int R;
+  BevGeom g;
+  float threshold, bit_scale;
+  ddp_step st;
+};
+int launch_bev_update(const BevUpdateArgs& a, hipStream_t st);
+
+}  // namespace ddp

@@ -1,0 +1,540 @@
+// ddp_kernels.hip - the memory-bound kernels of the DDP sampling loop (gfx950, wave64).
+//
+// All activations are token-major fp32 (rows = tokens, 256 contiguous channels = 1 KiB per row), so
+// one wave64 owns one token row as 64 x float4: every load / store of a row is a single fully
+// coalesced 1 KiB access and per-token reductions are wave reductions.
+#include <math.h>
+#include "ddp_internal.h"
+
+namespace ddp {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// NCHW (R, C, N) -> token-major (R, N, C): 64x64 tiles through LDS (stride 65: conflict-free both ways)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nchw_to_tok(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                      int N) {
+  __shared__ float tile[64][65];
+  const int r = blockIdx.z;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = in + size_t(r) * C * N;
+  float* dst = out + size_t(r) * N * C;
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, n = n0 + tx;
+    tile[cc][tx] = (c < C && n < N) ? src[size_t(c) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int nn = ty; nn < 64; nn += 4) {
+    const int n = n0 + nn, c = c0 + tx;
+    if (n < N && c < C) dst[size_t(n) * C + c] = tile[tx][nn];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deformable attention core (one level): one wave per token; lane = (head = lane>>3, 4 channels).
+// 8 lanes of a head read one 128-B line per bilinear tap; the wave writes its token's 1 KiB row.
+// Sample coordinates are already in pixel units (x = j + o_x, y = i + o_y): with one level the
+// (j+0.5)/w reference point, the /w normaliser and grid_sample's align_corners=False mapping cancel
+// (multi_scale_deform_attn.py:329-334,123-128).  Taps outside the map contribute 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_msda_gather(const float* __restrict__ value, const float* __restrict__ samp,
+                                                      float* __restrict__ out, int rows, int n_tok, int h, int w) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int hd = lane >> 3;
+  const int cq = (lane & 7) * 4;
+  const float* vbase = value + size_t(m / n_tok) * n_tok * 256 + hd * 32 + cq;
+  const float* sp = samp + size_t(m) * DDP_SAMP_STRIDE;
+  const f32x4 c01 = *reinterpret_cast<const f32x4*>(sp + hd * 8);
+  const f32x4 c23 = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
+  const f32x4 aw = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+  const float xs[4] = {c01[0], c01[2], c23[0], c23[2]};
+  const float ys[4] = {c01[1], c01[3], c23[1], c23[3]};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x = xs[p], y = ys[p];
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const int x0 = int(xf), y0 = int(yf);
+    const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x0 + 1 >= 0) & (x0 + 1 < w);
+    const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y0 + 1 >= 0) & (y0 + 1 < h);
+    const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1);
+    const int yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
+    const float w00 = (vx0 & vy0) ? (1.f - fy) * (1.f - fx) : 0.f;
+    const float w01 = (vx1 & vy0) ? (1.f - fy) * fx : 0.f;
+    const float w10 = (vx0 & vy1) ? fy * (1.f - fx) : 0.f;
+    const float w11 = (vx1 & vy1) ? fy * fx : 0.f;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc0 * w + xc0) * 256);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc0 * w + xc1) * 256);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc1 * w + xc0) * 256);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc1 * w + xc1) * 256);
+    const f32x4 s = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    acc += s * aw[p];
+  }
+  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + hd * 32 + cq) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// time embedding pieces (segmentors/ddp.py:41-46,107-112; utils/transformer.py:275-278)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sinusoid(const float* __restrict__ freq, const float* __restrict__ t_in, int S, float* __restrict__ u) {
+  const int s = blockIdx.x;
+  const int k = threadIdx.x;  // 0..16
+  if (s >= S || k >= DDP_SINU_FEATS) return;
+  const float x = t_in[s];
+  float v;
+  if (k == 0) {
+    v = x;
+  } else {
+    const int f = (k - 1) & 7;
+    const float fr = ((x * freq[f]) * 2.0f) * 3.14159265358979323846f;  // x * w * 2 * pi, left to right in fp32
+    v = (k <= 8) ? sinf(fr) : cosf(fr);
+  }
+  u[s * DDP_SINU_FEATS + k] = v;
+}
+
+// y[s][o] = out_act(W[o][:] . in_act(x[s][:]) + b[o]); one wave per (s, o)
+__global__ void __launch_bounds__(256) k_matvec(const float* __restrict__ W, const float* __restrict__ b,
+                                                 const float* __restrict__ x, float* __restrict__ y, int in_dim,
+                                                 int out_dim, int S, int ldx, int ldy, int in_act, int out_act) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= out_dim * S) return;
+  const int s = gw / out_dim, o = gw - s * out_dim;
+  const float* wr = W + size_t(o) * in_dim;
+  const float* xr = x + size_t(s) * ldx;
+  float acc = 0.f;
+  for (int k = lane; k < in_dim; k += 64) {
+    float xv = xr[k];
+    if (in_act == 2) xv = xv / (1.0f + expf(-xv));  // SiLU
+    acc += wr[k] * xv;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = acc + (b ? b[o] : 0.f);
+    if (out_act == 1) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    y[size_t(s) * ldy + o] = v;
+  }
+}
+
+// x0 look-up table: lut[k][c] = (sigmoid(E[k][c]) * 2 - 1) * bit_scale   (ddp.py:236-237)
+__global__ void k_build_lut(const float* __restrict__ emb, float* __restrict__ lut, int n, float bit_scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lut[i] = (sigmoidf_(emb[i]) * 2.0f - 1.0f) * bit_scale;
+}
+
+// Separable positional tables (utils/transformer.py:78-113 folded through sampling_offsets /
+// attention_weights):  PY[i][o] = b[o] + sum_{c<128} W[o][c] * pe_y(i,c);  PX[j][o] = sum_c W[o][128+c] * pe_x(j,c)
+// pe(p, c) = sin|cos( ((p + 1 - 0.5) / (len + 1e-6) * 2pi) / 10000^(2*(c/2)/128) ), sin for even c.
+// one wave per (row, o): rows 0..h-1 are PY, h..h+w-1 are PX.
+__global__ void __launch_bounds__(256) k_pos_tables(const float* __restrict__ wcat, const float* __restrict__ bcat,
+                                                     float* __restrict__ py, float* __restrict__ px, int h, int w) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (h + w) * 96) return;
+  const int row = gw / 96, o = gw - row * 96;
+  const bool is_y = row < h;
+  const int p = is_y ? row : row - h;
+  const float len = float(is_y ? h : w);
+  const float embed = (float(p + 1) + (-0.5f)) / (len + 1e-6f) * 6.283185307179586f;
+  const float* wr = wcat + o * 256 + (is_y ? 0 : 128);
+  float acc = 0.f;
+#pragma unroll
+  for (int c = lane; c < 128; c += 64) {
+    const float dim_t = powf(10000.0f, float(2 * (c / 2)) / 128.0f);
+    const float a = embed / dim_t;
+    const float pe = (c & 1) ? cosf(a) : sinf(a);
+    acc += wr[c] * pe;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (is_y) py[p * 96 + o] = acc + bcat[o];
+    else px[p * 96 + o] = acc;
+  }
+}
+
+__global__ void k_pack_rows(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                            float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) out[i] = a[i];
+  else if (i < na + nb) out[i] = b[i - na];
+}
+
+// out[r][c] = in[r*ld_in + off + c]  (split the concat-conv weight into its x / noisy-map column blocks)
+__global__ void k_pack_cols(const float* __restrict__ in, int ld_in, int off, int rows, int cols, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i - r * cols;
+  out[i] = in[size_t(r) * ld_in + off + c];
+}
+
+// conv_depth.weight (1,256,3,3) -> tap-major (9,256): out[dy*3+dx][c] = w[c][dy][dx]
+__global__ void k_pack_conv3x3(const float* __restrict__ w, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * 256) return;
+  const int t = i / 256, c = i - t * 256;
+  out[i] = w[c * 9 + t];
+}
+
+struct FloatList { float v[DDP_MAX_STEPS]; };
+__global__ void k_write_floats(FloatList f, int n, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < n) out[i] = f.v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// seg: argmax -> LUT -> DDIM / DDPM update of the noisy map, + softmax accumulation.
+// One wave per token.  (segmentors/ddp.py:235-245 ddim, :276-287 ddpm)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seg_update(SegUpdateArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.rows) return;
+  const float* lg = a.logits + size_t(m) * a.ldl;
+  const int K = a.num_classes;
+  // up to 256 classes: 4 per lane (k = lane + 64*q)
+  float v[4];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = lane + 64 * q;
+    v[q] = (k < K) ? lg[k] : -INFINITY;
+    if (k < K && (v[q] > best)) {   // strict >: keeps the first (smallest k) maximum within the lane
+      best = v[q];
+      bi = k;
+    }
+  }
+  // wave arg-max, ties -> smallest index (torch.argmax returns the first maximal element)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  if (a.prob && a.prob_mode) {
+    float* pr = a.prob + size_t(m) * a.ldl;
+    if (a.prob_mode == 3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < K) pr[k] = v[q];
+      }
+    } else {
+      float e[4], s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        e[q] = (k < K) ? expf(v[q] - best) : 0.f;
+        s += e[q];
+      }
+      s = wave_sum(s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < K) {
+          const float pv = e[q] / s;
+          pr[k] = (a.prob_mode == 2) ? pr[k] + pv : pv;
+        }
+      }
+    }
+  }
+  // x0 row and update of this token's 256 channels
+  const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.lut + size_t(bi) * 256 + lane * 4);
+  float* mp = a.mask + size_t(m) * 256 + lane * 4;
+  const f32x4 mt = *reinterpret_cast<const f32x4*>(mp);
+  f32x4 mn;
+  if (a.sampler == DDP_SAMPLER_DDIM) {
+    const float sig = fmaxf(a.st.sigma, 1e-8f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pn = (mt[e] - a.st.alpha * x0[e]) / sig;
+      mn[e] = x0[e] * a.st.alpha_next + pn * a.st.sigma_next;
+    }
+  } else {
+    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+    if (a.st.ddpm_add_noise && a.step_noise) nz = *reinterpret_cast<const f32x4*>(a.step_noise + size_t(m) * 256 + lane * 4);
+    const float c = a.st.ddpm_c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float mean = a.st.alpha_next * (mt[e] * (1.0f - c) / a.st.alpha + c * x0[e]);
+      mn[e] = mean + a.st.ddpm_std * nz[e];
+    }
+  }
+  *reinterpret_cast<f32x4*>(mp) = mn;
+}
+
+// out[b][k][n] = (sum_ri prob[(b*r+ri)*N + n][k]) / div ; block = 64 tokens, LDS transpose
+__global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__ prob, int ldl, float* __restrict__ out,
+                                                        int r, int N, int K, float div) {
+  extern __shared__ float tile[];  // [64][K+1]
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * 64;
+  const int ldt = K + 1;
+  for (int idx = threadIdx.x; idx < 64 * K; idx += 256) {
+    const int nn = idx / K, k = idx - nn * K;
+    const int n = n0 + nn;
+    float s = 0.f;
+    if (n < N)
+      for (int ri = 0; ri < r; ++ri) s += prob[(size_t(b * r + ri) * N + n) * ldl + k];
+    tile[nn * ldt + k] = s / div;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < K; k += 4) {
+    const int n = n0 + lane;
+    if (n < N) out[(size_t(b) * K + k) * N + n] = tile[lane * ldt + k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depth (depth/depth/models/depther/ddp.py:220-247; decode_heads/decode_head.py:264-269)
+// ------------------------------------------------------------------------------------------------
+// q[(b*r+ri)*N+n][c] = xproj[b*N+n][c] + wm[c] * d[(b*r+ri)*N+n]   (down conv over cat[x, depth_t], Cm = 1)
+__global__ void __launch_bounds__(256) k_feat_depth(const float* __restrict__ xproj, const float* __restrict__ wm,
+                                                     const float* __restrict__ d, float* __restrict__ q, int r, int N,
+                                                     int rows) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int b = m / (r * N), n = m % N;
+  const f32x4 xp = *reinterpret_cast<const f32x4*>(xproj + (size_t(b) * N + n) * 256 + lane * 4);
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(wm + lane * 4);
+  const float dv = d[m];
+  *reinterpret_cast<f32x4*>(q + size_t(m) * 256 + lane * 4) = xp + wv * dv;
+}
+
+// taps (M,32): column t = dy*3+dx holds w[:,dy,dx] . q[m]; depth[i][j] = relu(sum_t taps[(i+dy-1, j+dx-1)][t] + b) + eps
+__global__ void __launch_bounds__(256) k_depth_update(DepthUpdateArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = a.h * a.w;
+  if (m >= a.B_r * N) return;
+  const int img = m / N, n = m - img * N;
+  const int i = n / a.w, j = n - i * a.w;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ii = i + dy - 1, jj = j + dx - 1;
+      if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) s += a.taps[(size_t(img) * N + ii * a.w + jj) * 32 + dy * 3 + dx];
+    }
+  s += a.bias_ptr[0];
+  const float pred = fmaxf(s, 0.f) + a.eps_depth;
+  a.pred[m] = pred;
+  if (!a.depth_t) return;   // head-only call: no sampler update
+  float x0 = (pred - a.min_depth) / (a.max_depth - a.min_depth);
+  x0 = (x0 * 2.0f - 1.0f) * a.bit_scale;
+  x0 = fminf(fmaxf(x0, -a.bit_scale), a.bit_scale);
+  const float xt = a.depth_t[m];
+  const float eps = a.st.sigma * (xt - a.st.alpha * x0);   // sigma field = 1/sqrt(1-gamma_now)
+  a.depth_t[m] = a.st.alpha_next * x0 + a.st.sigma_next * eps;
+}
+
+__global__ void k_mean_r(const float* __restrict__ pred, float* __restrict__ out, int r, int N, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / N, n = idx - b * N;
+  float s = 0.f;
+  for (int ri = 0; ri < r; ++ri) s += pred[size_t(b * r + ri) * N + n];
+  out[idx] = s / float(r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bev (heads/segm/deformable_head_with_time.py:70-97; fusion_models/ddp.py:290-300)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bev_src_coord(const BevGeom& g, int axis, int k, int in_len) {
+  // c_k = first + k*step; normalised g = (c - imin)/(imax - imin)*2 - 1; pixel = ((g + 1)*len - 1)/2
+  const float c = g.out_first[axis] + float(k) * g.out_step[axis];
+  const float gn = (c - g.in_min[axis]) / (g.in_max[axis] - g.in_min[axis]) * 2.0f - 1.0f;
+  return ((gn + 1.0f) * float(in_len) - 1.0f) * 0.5f;
+}
+
+// bilinear (zeros padding, align_corners=False) resample of token-major feat (R, h*w, 256) onto (R, hh*wh, 256)
+__global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ feat, float* __restrict__ out, int R,
+                                                       BevGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Nh = g.hh * g.wh, N = g.h * g.w;
+  if (m >= R * Nh) return;
+  const int img = m / Nh, n = m - img * Nh;
+  const int oi = n / g.wh, oj = n - oi * g.wh;
+  const float y = bev_src_coord(g, 0, oi, g.h);
+  const float x = bev_src_coord(g, 1, oj, g.w);
+  const float xf = floorf(x), yf = floorf(y);
+  const float fx = x - xf, fy = y - yf;
+  const int x0 = int(xf), y0 = int(yf);
+  const float* base = feat + size_t(img) * N * 256 + lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx, yy = y0 + dy;
+      if (xx >= 0 && xx < g.w && yy >= 0 && yy < g.h) {
+        const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
+        acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
+      }
+    }
+  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = acc;
+}
+
+// (a) per head token: prob = sigmoid(logit), accumulate;  (b) per map token (h,w): nearest source in the
+// head grid, threshold -> class ids -> mean embedding -> x0 -> DDIM update.  Two launches of this kernel
+// body are avoided by doing (a) for all head tokens in blocks [0, nbA) and (b) in the rest.
+__global__ void __launch_bounds__(256) k_bev_update(BevUpdateArgs a, int nbA) {
+  const int lane = threadIdx.x & 63;
+  const int Nh = a.g.hh * a.g.wh, N = a.g.h * a.g.w;
+  const int K = a.num_classes;
+  if (int(blockIdx.x) < nbA) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.R * Nh * K) return;
+    const int m = idx / K, k = idx - m * K;
+    const float p = sigmoidf_(a.logits[size_t(m) * 32 + k]);
+    float* pr = a.prob + size_t(m) * 32 + k;
+    *pr = a.first ? p : (*pr + p);
+    return;
+  }
+  const int m = (blockIdx.x - nbA) * 4 + (threadIdx.x >> 6);
+  if (m >= a.R * N || !a.mask) return;
+  const int img = m / N, n = m - img * N;
+  const int i = n / a.g.w, j = n - i * a.g.w;
+  // F.interpolate(mode='nearest') (hh,wh) -> (h,w): src = min(floor(dst * (in/out)), in-1)
+  const int si = min(int(floorf(float(i) * (float(a.g.hh) / float(a.g.h)))), a.g.hh - 1);
+  const int sj = min(int(floorf(float(j) * (float(a.g.wh) / float(a.g.w)))), a.g.wh - 1);
+  const float* lg = a.logits + (size_t(img) * Nh + si * a.g.wh + sj) * 32;
+  f32x4 e = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    const int id = (sigmoidf_(lg[k]) > a.threshold) ? (k + 1) : 0;
+    e += *reinterpret_cast<const f32x4*>(a.emb + size_t(id) * 256 + lane * 4);
+  }
+  float* mp = a.mask + size_t(m) * 256 + lane * 4;
+  const f32x4 mt = *reinterpret_cast<const f32x4*>(mp);
+  const float sig = fmaxf(a.st.sigma, 1e-8f);
+  f32x4 mn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = (sigmoidf_(e[q] / float(K)) * 2.0f - 1.0f) * a.bit_scale;
+    const float pn = (mt[q] - a.st.alpha * x0) / sig;
+    mn[q] = x0 * a.st.alpha_next + pn * a.st.sigma_next;
+  }
+  *reinterpret_cast<f32x4*>(mp) = mn;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int cdiv(long a, long b) { return int((a + b - 1) / b); }
+
+int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_nchw_to_tok, dim3(cdiv(N, 64), cdiv(C, 64), R), dim3(256), 0, st, in, out, C, N);
+  return check_launch("k_nchw_to_tok");
+}
+int launch_msda_gather(const float* value, const float* samp, float* out, int rows, int n_tok, int h, int w,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_msda_gather, dim3(cdiv(rows, 4)), dim3(256), 0, st, value, samp, out, rows, n_tok, h, w);
+  return check_launch("k_msda_gather");
+}
+int launch_sinusoid(const float* freq, const float* t_in, int S, float* u, hipStream_t st) {
+  hipLaunchKernelGGL(k_sinusoid, dim3(S), dim3(64), 0, st, freq, t_in, S, u);
+  return check_launch("k_sinusoid");
+}
+int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,
+                  int ldx, int ldy, int in_act, int out_act, hipStream_t st) {
+  hipLaunchKernelGGL(k_matvec, dim3(cdiv(long(out_dim) * S, 4)), dim3(256), 0, st, W, b, x, y, in_dim, out_dim, S,
+                     ldx, ldy, in_act, out_act);
+  return check_launch("k_matvec");
+}
+int launch_build_lut(const float* emb, float* lut, int rows, float bit_scale, hipStream_t st) {
+  const int n = rows * 256;
+  hipLaunchKernelGGL(k_build_lut, dim3(cdiv(n, 256)), dim3(256), 0, st, emb, lut, n, bit_scale);
+  return check_launch("k_build_lut");
+}
+int launch_pos_tables(const float* wcat, const float* bcat, float* py, float* px, int h, int w, hipStream_t st) {
+  hipLaunchKernelGGL(k_pos_tables, dim3(cdiv(long(h + w) * 96, 4)), dim3(256), 0, st, wcat, bcat, py, px, h, w);
+  return check_launch("k_pos_tables");
+}
+int launch_pack_rows(const float* a, int rows_a, const float* b, int rows_b, float* out, int cols, hipStream_t st) {
+  const int na = rows_a * cols, nb = rows_b * cols;
+  hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(na + nb, 256)), dim3(256), 0, st, a, na, b, nb, out);
+  return check_launch("k_pack_rows");
+}
+int launch_pack_cols(const float* in, int ld_in, int off, int rows, int cols, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_cols, dim3(cdiv(long(rows) * cols, 256)), dim3(256), 0, st, in, ld_in, off, rows, cols, out);
+  return check_launch("k_pack_cols");
+}
+int launch_pack_conv3x3(const float* w, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_conv3x3, dim3(9), dim3(256), 0, st, w, out);
+  return check_launch("k_pack_conv3x3");
+}
+int launch_write_floats(const float* host_vals, int n, float* out, hipStream_t st) {
+  FloatList f;
+  for (int i = 0; i < DDP_MAX_STEPS; ++i) f.v[i] = i < n ? host_vals[i] : 0.f;
+  hipLaunchKernelGGL(k_write_floats, dim3(1), dim3(64), 0, st, f, n, out);
+  return check_launch("k_write_floats");
+}
+int launch_seg_update(const SegUpdateArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_update, dim3(cdiv(a.rows, 4)), dim3(256), 0, st, a);
+  return check_launch("k_seg_update");
+}
+int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
+                         hipStream_t st) {
+  const size_t lds = size_t(64) * (K + 1) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_nchw), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        64 * 257 * int(sizeof(float)));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_finalize_nchw, dim3(cdiv(N, 64), B), dim3(256), lds, st, prob, ldl, out, r, N, K, div);
+  return check_launch("k_finalize_nchw");
+}
+int launch_feat_depth(const float* xproj, const float* wm, const float* d, float* q, int B, int r, int N,
+                      hipStream_t st) {
+  const int rows = B * r * N;
+  hipLaunchKernelGGL(k_feat_depth, dim3(cdiv(rows, 4)), dim3(256), 0, st, xproj, wm, d, q, r, N, rows);
+  return check_launch("k_feat_depth");
+}
+int launch_depth_update(const DepthUpdateArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_depth_update, dim3(cdiv(long(a.B_r) * a.h * a.w, 256)), dim3(256), 0, st, a);
+  return check_launch("k_depth_update");
+}
+int launch_mean_r(const float* pred, float* out, int B, int r, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_mean_r, dim3(cdiv(long(B) * N, 256)), dim3(256), 0, st, pred, out, r, N, B * N);
+  return check_launch("k_mean_r");
+}
+int launch_bev_resample(const float* feat, float* out, int R, const BevGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL(k_bev_resample, dim3(cdiv(long(R) * g.hh * g.wh, 4)), dim3(256), 0, st, feat, out, R, g);
+  return check_launch("k_bev_resample");
+}
+int launch_bev_update(const BevUpdateArgs& a, hipStream_t st) {
+  const int nbA = cdiv(long(a.R) * a.g.hh * a.g.wh * a.num_classes, 256);
+  const int nbB = cdiv(long(a.R) * a.g.h * a.g.w, 4);
+  hipLaunchKernelGGL(k_bev_update, dim3(nbA + nbB), dim3(256), 0, st, a, nbA);
+  return check_launch("k_bev_update");
+}
+
+}  // namespace ddp

@@ -1,0 +1,196 @@
+"""DDPEngine: owns the device-side state of one configured sampling problem and calls the C ABI.
+
+PyTorch is plumbing here: it allocates device memory (weights blob, workspace, inputs/outputs) and
+provides the current HIP stream; every FLOP of the loop runs in libddp_mi355x.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import schedule
+
+TASKS = {'seg': _lib.TASK_SEG, 'depth': _lib.TASK_DEPTH, 'bev': _lib.TASK_BEV}
+SAMPLERS = {'ddim': _lib.SAMPLER_DDIM, 'ddpm': _lib.SAMPLER_DDPM}
+
+_LAYER_KEYS = {
+    'sampling_offsets_w': 'attentions.0.sampling_offsets.weight', 'sampling_offsets_b': 'attentions.0.sampling_offsets.bias',
+    'attention_weights_w': 'attentions.0.attention_weights.weight', 'attention_weights_b': 'attentions.0.attention_weights.bias',
+    'value_proj_w': 'attentions.0.value_proj.weight', 'value_proj_b': 'attentions.0.value_proj.bias',
+    'output_proj_w': 'attentions.0.output_proj.weight', 'output_proj_b': 'attentions.0.output_proj.bias',
+    'ffn0_w': 'ffns.0.layers.0.0.weight', 'ffn0_b': 'ffns.0.layers.0.0.bias',
+    'ffn1_w': 'ffns.0.layers.1.weight', 'ffn1_b': 'ffns.0.layers.1.bias',
+    'norm0_w': 'norms.0.weight', 'norm0_b': 'norms.0.bias', 'norm1_w': 'norms.1.weight', 'norm1_b': 'norms.1.bias',
+    'time_w': 'time_mlp.1.weight', 'time_b': 'time_mlp.1.bias',
+}
+
+
+def hot_path_keys(task, num_layers, head_prefix='decode_head.'):
+    """(struct field, state_dict key) pairs of the hot path (SURVEY.md §8b checkpoint layout)."""
+    conv = 'down.conv' if task == 'depth' else 'transform.conv'
+    top = [('transform_w', conv + '.weight'), ('transform_b', conv + '.bias'),
+           ('time_freq', 'time_mlp.0.weights'), ('time1_w', 'time_mlp.1.weight'), ('time1_b', 'time_mlp.1.bias'),
+           ('time3_w', 'time_mlp.3.weight'), ('time3_b', 'time_mlp.3.bias')]
+    if task != 'depth':
+        top.append(('embedding', 'embedding_table.weight'))
+    hc = 'conv_depth' if task == 'depth' else 'conv_seg'
+    top += [('head_w', head_prefix + hc + '.weight'), ('head_b', head_prefix + hc + '.bias')]
+    layers = []
+    for l in range(num_layers):
+        p = f'{head_prefix}encoder.layers.{l}.'
+        layers.append([(f, p + k) for f, k in _LAYER_KEYS.items()])
+    return top, layers
+
+
+def count_layers(state_dict, head_prefix='decode_head.'):
+    n = 0
+    while f'{head_prefix}encoder.layers.{n}.norms.0.weight' in state_dict:
+        n += 1
+    return n
+
+
+class PackedWeights:
+    """All hot-path parameters in ONE flat fp32 device buffer (256-byte aligned sub-tensors): a
+    single allocation, a single RCCL broadcast, and stable pointers for the ``ddp_weights`` table."""
+
+    def __init__(self, state_dict, task, num_layers, device, head_prefix='decode_head.'):
+        top, layers = hot_path_keys(task, num_layers, head_prefix)
+        entries = []
+        for f, k in top:
+            entries.append((None, f, k))
+        for l, lk in enumerate(layers):
+            for f, k in lk:
+                entries.append((l, f, k))
+        offs, total = {}, 0
+        for l, f, k in entries:
+            if k not in state_dict:
+                if f in ('time_w', 'time_b'):     # layer built without use_time_mlp
+                    continue
+                raise KeyError(f'hot-path parameter {k!r} missing from state_dict')
+            n = state_dict[k].numel()
+            offs[(l, f)] = (total, k)
+            total += (n + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32)
+        for (l, f), (o, k) in offs.items():
+            flat[o:o + state_dict[k].numel()] = state_dict[k].detach().reshape(-1).to(torch.float32).cpu()
+        self.flat = flat.to(device)
+        self.offsets = offs
+        self.task = task
+        self.num_layers = num_layers
+        self.struct = self._build_struct()
+
+    def _build_struct(self):
+        w = _lib.DdpWeights()
+        base = self.flat.data_ptr()
+        for (l, f), (o, _) in self.offsets.items():
+            tgt = w if l is None else w.layers[l]
+            setattr(tgt, f, base + 4 * o)
+        return w
+
+    def broadcast(self, src=0):
+        """Replicate the frozen weights from rank ``src`` to every rank (RCCL over xGMI; the only
+        collective of the inference path - SURVEY.md §8e)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat, src=src)
+
+
+class DDPEngine:
+    """One configured problem: (task, sizes, schedule) + weights + workspace."""
+
+    def __init__(self, state_dict, task='seg', *, h, w, batch=1, randsteps=1, timesteps=3, num_classes=150,
+                 feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
+                 sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
+                 head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
+                 weights=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.task = task
+        num_layers = count_layers(state_dict, head_prefix) if weights is None else weights.num_layers
+        self.weights = weights if weights is not None else PackedWeights(state_dict, task, num_layers, self.device,
+                                                                        head_prefix)
+        cfg = _lib.DdpCfg()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.task = TASKS[task]
+        cfg.sampler = SAMPLERS[sampler]
+        cfg.batch, cfg.randsteps, cfg.timesteps, cfg.num_layers = batch, randsteps, timesteps, num_layers
+        cfg.num_classes = 1 if task == 'depth' else num_classes
+        cfg.feat_channels = feat_channels
+        cfg.h, cfg.w = h, w
+        if task == 'bev':
+            if bev_input_scope is None or bev_output_scope is None:
+                raise ValueError('bev needs bev_input_scope / bev_output_scope (grid_transform of the head)')
+            out_sizes = []
+            for a, ((imin, imax, _), (omin, omax, ostep)) in enumerate(zip(bev_input_scope, bev_output_scope)):
+                n = int(torch.arange(omin + ostep / 2, omax, ostep).numel())
+                out_sizes.append(n)
+                cfg.bev_in_min[a], cfg.bev_in_max[a] = imin, imax
+                cfg.bev_out_first[a], cfg.bev_out_step[a] = omin + ostep / 2, ostep
+            cfg.head_h, cfg.head_w = out_sizes
+        else:
+            cfg.head_h, cfg.head_w = (h, w) if head_hw is None else head_hw
+        cfg.accumulation = int(bool(accumulation))
+        cfg.bit_scale, cfg.min_depth, cfg.max_depth, cfg.threshold = bit_scale, min_depth, max_depth, threshold
+        self.cfg = cfg
+        self.sampler = sampler
+        recs = schedule.step_records(task, timesteps, time_difference, sample_range0, noise_schedule, sampler)
+        self.steps = (_lib.DdpStep * timesteps)()
+        for i, r in enumerate(recs):
+            for k, v in r.items():
+                setattr(self.steps[i], k, v)
+        nbytes = C.c_size_t(0)
+        _lib.check(self.lib.ddp_query_workspace(C.byref(cfg), C.byref(nbytes)))
+        self.workspace = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        self._prepared = False
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def out_shape(self):
+        c = self.cfg
+        if self.task == 'depth':
+            return (c.batch, 1, c.h, c.w)
+        return (c.batch, c.num_classes, c.head_h, c.head_w)
+
+    def prepare(self):
+        _lib.check(self.lib.ddp_prepare(C.byref(self.cfg), C.byref(self.weights.struct), self.steps,
+                                        self.workspace.data_ptr(), self._stream()))
+        self._prepared = True
+
+    def sample(self, x, noise, step_noise=None, out=None):
+        """x (B,Cx,h,w); noise (B,r,Cm,h,w); step_noise (K,B,r,Cm,h,w) for ddpm -> output tensor."""
+        c = self.cfg
+        cm = 1 if self.task == 'depth' else 256
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert tuple(x.shape) == (c.batch, c.feat_channels, c.h, c.w), (tuple(x.shape), (c.batch, c.feat_channels, c.h, c.w))
+        assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+        assert noise.numel() == c.batch * c.randsteps * cm * c.h * c.w
+        if self.sampler == 'ddpm':
+            assert step_noise is not None and step_noise.is_contiguous() and step_noise.numel() == c.timesteps * noise.numel()
+        if not self._prepared:
+            self.prepare()
+        if out is None:
+            out = torch.empty(self.out_shape(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ddp_sample(C.byref(c), C.byref(self.weights.struct), self.steps, x.data_ptr(),
+                                       noise.data_ptr(), step_noise.data_ptr() if step_noise is not None else None,
+                                       out.data_ptr(), self.workspace.data_ptr(), self._stream()))
+        return out
+
+    def head_forward(self, feat, temb):
+        """DeformableHeadWithTime.forward on (R,256,h,w) + (1|R,1024) time embedding."""
+        c = self.cfg
+        R = c.batch * c.randsteps
+        assert feat.is_cuda and feat.is_contiguous() and tuple(feat.shape) == (R, 256, c.h, c.w)
+        t = None
+        if temb is not None:
+            t = temb.reshape(-1, 1024)[0].contiguous()
+        shape = (R, 1, c.h, c.w) if self.task == 'depth' else (R, c.num_classes, c.head_h, c.head_w)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ddp_head_forward(C.byref(c), C.byref(self.weights.struct), feat.data_ptr(),
+                                             t.data_ptr() if t is not None else None, out.data_ptr(),
+                                             self.workspace.data_ptr(), self._stream()))
+        self._prepared = False      # head_forward rewrites the FiLM slot of step 0
+        return out

@@ -1,0 +1,162 @@
+/* ddp_mi355x.h - C ABI of libddp_mi355x.so: the MI355X (gfx950) implementation of the DDP
+ * multi-step denoising inference loop.
+ *
+ * The reference has no FFI for this path: the loop is Python/torch
+ * (segmentation/mmseg/models/segmentors/ddp.py:215-246 `DDP.ddim_sample`, :248-290 `ddpm_sample`;
+ * depth/depth/models/depther/ddp.py:229-247 `DDP.sample`;
+ * bev/mmdet3d/models/fusion_models/ddp.py:268-301 `DDP.ddim_sample`) calling
+ * `DeformableHeadWithTime.forward` (segmentation/mmseg/models/decode_heads/deformable_head_with_time.py:90-132)
+ * and, below it, mmcv's only custom kernel `ext_module.ms_deform_attn_forward`
+ * (controlnet/annotator/uniformer/mmcv/ops/multi_scale_deform_attn.py:47-53).  This header is the
+ * boundary a maintainer would bind instead (ctypes stub: INTEGRATION.md); `ddp_amd`'s registered
+ * drop-in classes call exactly these symbols.
+ *
+ * Conventions
+ *  - plain C, no torch types.  Every pointer named `d_*` or living in `ddp_weights` is a DEVICE
+ *    pointer to contiguous fp32, 16-byte aligned.  The caller (PyTorch) owns every buffer,
+ *    including the workspace; the library never allocates or frees device memory.
+ *  - all work is enqueued on the `hipStream_t` passed as `void* stream` (0 = default stream);
+ *    no host synchronisation happens inside any entry point.
+ *  - return value: DDP_OK (0) or a negative DDP_E_* code; `ddp_last_error()` gives a message.
+ *    No exception crosses the boundary.
+ *  - thread-safety: re-entrant per (workspace, stream); no global mutable state except the
+ *    thread-local last-error string.
+ *  - fixed architecture constants of the reference configs: embed 256, 8 heads x 32, 4 points,
+ *    1 level, FFN 1024, time dim 1024, 16 learned sinusoid features.
+ */
+#ifndef DDP_MI355X_H
+#define DDP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDP_ABI_VERSION 1
+#define DDP_MAX_LAYERS 12
+#define DDP_MAX_STEPS 64
+#define DDP_EMBED 256
+#define DDP_HEADS 8
+#define DDP_POINTS 4
+#define DDP_FFN 1024
+#define DDP_TIME_DIM 1024
+#define DDP_SINU_FEATS 17 /* 1 + 16 */
+#define DDP_SAMP_STRIDE 96 /* per token: 64 sample coords (head,point,xy) + 32 weights */
+
+enum { DDP_OK = 0, DDP_E_BADCFG = -1, DDP_E_ALIGN = -2, DDP_E_LAUNCH = -3, DDP_E_NULL = -4 };
+enum { DDP_TASK_SEG = 0, DDP_TASK_DEPTH = 1, DDP_TASK_BEV = 2 };
+enum { DDP_SAMPLER_DDIM = 0, DDP_SAMPLER_DDPM = 1 };
+
+/* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
+ * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
+typedef struct ddp_cfg {
+  int32_t abi_version;    /* must be DDP_ABI_VERSION */
+  int32_t task;           /* DDP_TASK_* */
+  int32_t sampler;        /* DDP_SAMPLER_* (ddpm: seg only) */
+  int32_t batch;          /* B independent images (the reference loop is b = 1 per call) */
+  int32_t randsteps;      /* r noise replicas per image */
+  int32_t timesteps;      /* K sampling steps, <= DDP_MAX_STEPS */
+  int32_t num_layers;     /* L encoder layers, <= DDP_MAX_LAYERS */
+  int32_t num_classes;    /* K_cls (seg, bev <= 256); ignored for depth */
+  int32_t feat_channels;  /* channels of x (multiple of 32) */
+  int32_t h, w;           /* spatial size of x / of the noisy map */
+  int32_t head_h, head_w; /* token grid of the encoder: == h,w except bev (grid transform output) */
+  int32_t accumulation;   /* seg: average softmax over steps (ddp.py:241-245); bev always accumulates */
+  float bit_scale;
+  float min_depth, max_depth; /* depth */
+  float threshold;            /* bev x0 threshold (fusion_models/ddp.py:290) */
+  /* bev grid transform (heads/segm/deformable_head_with_time.py:70-97): per axis (y then x)
+   * input [min,max], output first centre and step: c_k = out_first + k * out_step */
+  float bev_in_min[2], bev_in_max[2], bev_out_first[2], bev_out_step[2];
+} ddp_cfg;
+
+typedef struct ddp_layer_weights {            /* decode_head.encoder.layers.<l>.* */
+  const float *sampling_offsets_w, *sampling_offsets_b;   /* (64,256),(64)  attentions.0.sampling_offsets */
+  const float *attention_weights_w, *attention_weights_b; /* (32,256),(32)  attentions.0.attention_weights */
+  const float *value_proj_w, *value_proj_b;               /* (256,256),(256) */
+  const float *output_proj_w, *output_proj_b;             /* (256,256),(256) */
+  const float *ffn0_w, *ffn0_b;                           /* (1024,256),(1024) ffns.0.layers.0.0 */
+  const float *ffn1_w, *ffn1_b;                           /* (256,1024),(256)  ffns.0.layers.1 */
+  const float *norm0_w, *norm0_b, *norm1_w, *norm1_b;     /* (256) each        norms.{0,1} */
+  const float *time_w, *time_b;                           /* (512,1024),(512)  time_mlp.1 ; may be NULL */
+} ddp_layer_weights;
+
+typedef struct ddp_weights {
+  const float *transform_w, *transform_b; /* (256, Cx+Cm) 1x1 conv as matrix, (256): transform.conv / down.conv */
+  const float *time_freq;                 /* (8)         time_mlp.0.weights */
+  const float *time1_w, *time1_b;         /* (1024,17),(1024) time_mlp.1 */
+  const float *time3_w, *time3_b;         /* (1024,1024),(1024) time_mlp.3 */
+  const float *embedding;                 /* (K_cls+1,256) embedding_table.weight; NULL for depth */
+  const float *head_w, *head_b;           /* seg/bev conv_seg (K_cls,256),(K_cls); depth conv_depth (1,256,3,3),(1) */
+  ddp_layer_weights layers[DDP_MAX_LAYERS];
+} ddp_weights;
+
+/* Host-computed per-step schedule scalars.  The cosine log-SNR is ill-conditioned at t = 1, so the
+ * Python host layer evaluates the schedule with torch CPU fp32 ops in the reference's op order
+ * (segmentors/ddp.py:22-28,225-231) and hands the scalars over; the library never re-derives them.
+ *   seg/bev : time_in = log_snr(t_now); alpha, sigma, alpha_next, sigma_next as in ddp.py:229-231
+ *   depth   : time_in = t_now; alpha = sqrt(gamma_now), sigma = 1/sqrt(1-gamma_now),
+ *             alpha_next = sqrt(gamma_next), sigma_next = sqrt(1-gamma_next)  (depther/ddp.py:220-227)
+ *   ddpm    : ddpm_c = -expm1(ls - ls_next), ddpm_std = exp(0.5*log(max(sigma_next^2*c,1e-20))),
+ *             ddpm_add_noise = (t_next > 0)                                     (ddp.py:276-284) */
+typedef struct ddp_step {
+  float time_in, alpha, sigma, alpha_next, sigma_next, ddpm_c, ddpm_std;
+  int32_t ddpm_add_noise;
+} ddp_step;
+
+const char* ddp_last_error(void);
+int ddp_abi_version(void);
+
+/* Size in bytes of the caller-provided workspace for `cfg` (constants + activations). */
+int ddp_query_workspace(const ddp_cfg* cfg, size_t* bytes);
+
+/* Fill the constant region of the workspace: time embeddings and per-layer FiLM vectors for every
+ * step (ddp.py:31-46,107-112; utils/transformer.py:275-278), sine positional tables folded through
+ * the offset/attention projections (utils/transformer.py:78-113), the x0 look-up table
+ * (ddp.py:236-237) and packed projection weights.  Must be re-run when weights, (h,w) or the
+ * schedule change; `steps` is a HOST array of cfg->timesteps entries. */
+int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps,
+                void* d_workspace, void* stream);
+
+/* The whole K-step loop for B images: replaces DDP.ddim_sample / ddpm_sample / sample.
+ *   d_x          (B, Cx, h, w)           frozen neck feature, NCHW
+ *   d_noise      (B, r, Cm, h, w)        start noise (the reference draws torch.randn in-method)
+ *   d_step_noise (K, B, r, Cm, h, w)     per-step noise, ddpm only, else NULL
+ *   d_out        seg: (B, K_cls, h, w); depth: (B, 1, h, w); bev: (B, K_cls, head_h, head_w) */
+int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps,
+               const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
+               void* d_workspace, void* stream);
+
+/* ---- finer-grained entry points (unit tests, and the decode_head plugin surface) ------------- */
+
+/* DeformableHeadWithTime.forward: feat (R,256,hh,wh) NCHW + time embedding (1024) -> head output
+ * seg: logits (R,K_cls,hh,wh); depth: metric depth (R,1,hh,wh); bev: sigmoid maps.  Uses step slot 0
+ * of the workspace constants for FiLM, recomputed from d_temb.  R = batch*randsteps. */
+int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float* d_feat,
+                     const float* d_temb, float* d_out, void* d_workspace, void* stream);
+
+/* One deformable attention core (mmcv ms_deform_attn_forward for 1 level):
+ *   d_value (R, N, 256) token-major; d_samp (R*N, 96): per token 64 pixel-unit sample coordinates
+ *   [head][point][x,y] followed by 32 softmaxed weights [head][point]; d_out (R*N, 256). */
+int ddp_msda_forward(const float* d_value, const float* d_samp, float* d_out, int rows, int h, int w,
+                     void* stream);
+
+/* out[M][N] = A[M][K] * W[N][K]^T + bias  (fp32 MFMA), optional exact GELU. K % 32 == 0. */
+int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k,
+               int gelu, void* stream);
+
+/* time_mlp + per-layer FiLM on device: d_temb (S,1024), d_film (S,L,512) for S time inputs. */
+int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time_in_host, int s,
+                   float* d_temb, float* d_film, float* d_scratch /* >= S*(17+1024) floats */, void* stream);
+
+/* DDIM x0-projection + update for seg on token-major buffers (ddp.py:235-239):
+ *   d_logits (M, ld_logits), d_lut (K_cls+1... rows of 256), d_mask (M,256) updated in place. */
+int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, const float* d_lut,
+                        float* d_mask, int rows, const ddp_step* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDP_MI355X_H */
