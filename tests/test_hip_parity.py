@@ -79,7 +79,8 @@ def test_linear_transpose_detect(dev):
     a = torch.eye(m, k)
     w = torch.arange(n * k, dtype=torch.float32).reshape(n, k) / (n * k)
     out = torch.empty(m, n, device=dev)
-    _lib.check(lib.ddp_linear(a.to(dev).data_ptr(), w.to(dev).data_ptr(), None, out.data_ptr(), m, n, k, 0,
+    da, dw = a.to(dev), w.to(dev)       # keep the device copies alive across the call
+    _lib.check(lib.ddp_linear(da.data_ptr(), dw.data_ptr(), None, out.data_ptr(), m, n, k, 0,
                               torch.cuda.current_stream().cuda_stream))
     assert torch.equal(out.cpu(), w.t().contiguous())
 
@@ -108,8 +109,9 @@ def test_msda_forward(dev, h, w, r):
     assert max_rel(ref, ref2) < 1e-5
     samp = torch.cat([torch.stack((px, py), -1).reshape(r * n, 64), aw.reshape(r * n, 32)], 1).contiguous()
     out = torch.empty(r * n, 256, device=dev)
-    _lib.check(lib.ddp_msda_forward(value.reshape(r * n, 256).to(dev).data_ptr(), samp.to(dev).data_ptr(),
-                                    out.data_ptr(), r * n, h, w, torch.cuda.current_stream().cuda_stream))
+    dv, ds = value.reshape(r * n, 256).to(dev), samp.to(dev)
+    _lib.check(lib.ddp_msda_forward(dv.data_ptr(), ds.data_ptr(), out.data_ptr(), r * n, h, w,
+                                    torch.cuda.current_stream().cuda_stream))
     assert max_rel(out.cpu().reshape(r, n, 256), ref) < 1e-5
 
 
@@ -160,7 +162,8 @@ def test_sample_golden(dev, name):
     cfg, sd, x, noise, step_noise, g = load_case(name)
     eng = _engine(cfg, sd, dev)
     sn = step_noise.unsqueeze(1).contiguous().to(dev) if step_noise is not None else None
-    out = eng.sample(x.to(dev), noise.unsqueeze(0).contiguous().to(dev), sn)
+    dx, dn = x.to(dev), noise.unsqueeze(0).contiguous().to(dev)
+    out = eng.sample(dx, dn, sn)
     torch.cuda.synchronize()
     ref = g['out']
     assert out.shape == ref.shape
@@ -185,7 +188,8 @@ def test_sample_batch_matches_per_image_oracle(dev):
     cfg = dict(task='seg', h=h, w=w, randsteps=r, timesteps=3, bit_scale=0.01, num_classes=150, accumulation=True,
                noise_schedule='cosine', diffusion='ddim')
     eng = _engine(cfg, sd, dev, batch=B)
-    out = eng.sample(x.to(dev), noise.to(dev)).cpu()
+    dx, dn = x.to(dev), noise.to(dev)
+    out = eng.sample(dx, dn).cpu()
     for b in range(B):
         ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=3, randsteps=r, bit_scale=0.01, accumulation=True)
         assert max_rel(out[b:b + 1], ref) < REL
