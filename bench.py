@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py - images/s of the DDP K-step DDIM decoder loop on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 launched by
+torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path over one batch =
+``ddim_sample`` of B independent images (BASELINE.json configs[1]: ADE20K Swin-T decode head,
+3-step DDIM, batch 8 x 512x1024 -> x (8,256,128,256), 150 classes) with inputs already resident in
+HBM.  Images shard across ranks with no data-path collective (weak scaling: B images per GPU); the
+only collective is the one-off RCCL broadcast of the frozen weights (outside the timed region).
+
+Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the FFN fc2 GEMM + residual +
+LayerNorm + FiLM epilogue (k_gemm_tok<8,EpiResLN,TAG_FC2_LN>; FFN = 74 % of the loop's flops,
+fp32-MFMA-bound), timed live with HIP events around each of its launches in a second pass of the
+same workload.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
+parity-pinned to golden vectors) timed on this box's host cores on a bounded sample (single
+512x1024 images of the same workload), rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ddp_amd import _lib  # noqa: E402
+from ddp_amd.engine import DDPEngine, PackedWeights  # noqa: E402
+from ddp_amd.utils import synthetic  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    'ade_swin_t_k3_8x512x1024': dict(task='seg', batch=8, h=128, w=256, timesteps=3, randsteps=1, num_classes=150,
+                                     bit_scale=0.01, accumulation=True, num_layers=6),
+    'ade_swin_t_k1_1x512x512': dict(task='seg', batch=1, h=128, w=128, timesteps=1, randsteps=1, num_classes=150,
+                                    bit_scale=0.01, accumulation=True, num_layers=6),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+TAG_FC2_LN = 7
+
+
+def flops_per_token_step(num_layers, num_classes, cx=256):
+    """dense contractions only, 1 MAC = 2 flop."""
+    c = 256
+    per_layer = 2 * c * c + 2 * c * 64 + 2 * c * 32 + 2 * c * c + 4 * c * 1024
+    return 2 * c * (cx + c) + num_layers * per_layer + 2 * c * num_classes
+
+
+def usable_cores():
+    """host cores this process may actually use (cgroup cpu quota, else affinity / cpu_count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='ade_swin_t_k3_8x512x1024', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=2, help='images timed on the CPU oracle (bounded sample)')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    B, h, w, K = wl['batch'], wl['h'], wl['w'], wl['timesteps']
+    # frozen weights: generated on rank 0, replicated by ONE RCCL broadcast of the packed blob
+    sd = synthetic.make_state_dict('seg', wl['num_classes'], wl['num_layers'], 256, seed=2)
+    weights = PackedWeights(sd, 'seg', wl['num_layers'], dev)
+    if dist_on:
+        if rank != 0:
+            weights.flat.zero_()
+        weights.broadcast(src=0)
+    eng = DDPEngine(sd, 'seg', h=h, w=w, batch=B, randsteps=wl['randsteps'], timesteps=K,
+                    num_classes=wl['num_classes'], bit_scale=wl['bit_scale'], accumulation=wl['accumulation'],
+                    device=dev, weights=weights)
+    # synthetic inputs, distinct per rank (independent images), resident in HBM before timing
+    x, noise = synthetic.make_inputs(B, h, w, wl['randsteps'], 256, 256, seed=1000 * rank)
+    dx, dn = x.to(dev), noise.to(dev)
+    out = torch.empty(eng.out_shape(), dtype=torch.float32, device=dev)
+    eng.prepare()
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.sample(dx, dn, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sample(dx, dn, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    images_per_s = B * world * args.steps / elapsed
+
+    # ---- roofline leg: HIP events around every launch of the dominant kernel, same workload ----------
+    roofline = None
+    M = B * wl['randsteps'] * h * w
+    if not args.no_roofline:
+        lib = _lib.load()
+        _lib.check(lib.ddp_profile_begin(TAG_FC2_LN))
+        reps = min(args.steps, 3)
+        for _ in range(reps):
+            eng.sample(dx, dn, out=out)
+        tot, n = C.c_float(0), C.c_int(0)
+        _lib.check(lib.ddp_profile_end(C.byref(tot), C.byref(n)))
+        torch.cuda.synchronize()
+        avg_ms = tot.value / max(n.value, 1)
+        flops_launch = 2.0 * 256 * 1024 * M            # fc2: (M,1024) x (256,1024)^T, algorithmic
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+        roofline = dict(bound='mfma', kernel='k_gemm_tok<8,EpiResLN,TAG_FC2_LN> (FFN fc2 + residual + LN + FiLM)',
+                        achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches=n.value, avg_launch_ms=round(avg_ms, 4),
+                        flops_per_launch=flops_launch)
+        # whole-loop dense-contraction rate for context
+        loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes']) * float(M) * K
+        roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
+        roofline['loop_frac'] = round(roofline['loop_tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)
+
+    # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ddp_oracle as O
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        n_img = max(1, min(args.cpu_images, B))
+        gpu_out = out.cpu()
+        tcpu = 0.0
+        worst, agree, bad_px = 0.0, 1.0, 0
+        for b in range(n_img):
+            t1 = time.perf_counter()
+            ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=wl['randsteps'],
+                                    bit_scale=wl['bit_scale'], accumulation=wl['accumulation'])
+            tcpu += time.perf_counter() - t1
+            rel = (gpu_out[b:b + 1] - ref).abs().amax(1) / ref.abs().max()
+            worst = max(worst, float(rel.max()))
+            bad_px += int((rel > 1e-4).sum())
+            agree = min(agree, float((gpu_out[b:b + 1].argmax(1) == ref.argmax(1)).float().mean()))
+        cpu = dict(value=round(n_img / tcpu, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                   sample=f'{n_img} x (1x512x1024, {K}-step DDIM, 150 classes) of the same synthetic workload, '
+                          f'torch CPU fp32 oracle, {tcpu:.1f} s')
+        parity = dict(max_rel_vs_oracle=worst, argmax_agreement=agree, images_checked=n_img,
+                      pixels_above_1e-4=bad_px, gate=1e-3)
+
+    if rank == 0:
+        line = {
+            'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node',
+            'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload + ' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
+                                                   'per GPU; x (8,256,128,256), random-init weights)',
+                       'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
+                       'parallelism': f'dp{world} (independent images, weights broadcast once)'},
+            'images_per_s_per_gpu': round(images_per_s / world, 3),
+            'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -29,6 +29,27 @@ int check_launch(const char* what) {
   return DDP_OK;
 }
 
+// ---- optional event profiler of one GEMM call site (bench.py roofline leg) ----------------------
+namespace {
+constexpr int PROF_MAX = 512;
+struct Prof {
+  int tag = -1;
+  int n = 0;
+  hipEvent_t ev[2 * PROF_MAX];
+  bool created = false;
+} g_prof;
+}  // namespace
+
+void prof_begin(int tag, hipStream_t st) {
+  if (tag != g_prof.tag || g_prof.n >= PROF_MAX) return;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+}
+void prof_end(int tag, hipStream_t st) {
+  if (tag != g_prof.tag || g_prof.n >= PROF_MAX) return;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+  ++g_prof.n;
+}
+
 #define DDP_TRY(expr)            \
   do {                           \
     int _rc = (expr);            \
@@ -257,18 +278,18 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* film, hi
   for (int l = 0; l < o.L; ++l) {
     const ddp_layer_weights& lw = w->layers[l];
     // value / sampling projections (multi_scale_deform_attn.py:313-328)
-    DDP_TRY(launch_linear(o.q, 256, lw.value_proj_w, 256, lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, 0, st));
+    DDP_TRY(launch_linear(o.q, 256, lw.value_proj_w, 256, lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, 0, st, TAG_VALUE));
     DDP_TRY(launch_linear_samp(o.q, 256, o.wcat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
     // bilinear gather + weighted sum (:94-151)
     DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
     // output_proj + identity, LayerNorm (:352-358; utils/transformer.py:390-392)
     DDP_TRY(launch_linear_res_ln(o.s, 256, lw.output_proj_w, 256, lw.output_proj_b, o.q, 256, lw.norm0_w, lw.norm0_b,
-                                 nullptr, o.q1, 256, M, 256, st));
+                                 nullptr, o.q1, 256, M, 256, st, TAG_OUTPROJ_LN));
     // FFN + identity, LayerNorm, FiLM (mmcv FFN :269-280; utils/transformer.py:413-417)
-    DDP_TRY(launch_linear(o.q1, 256, lw.ffn0_w, 256, lw.ffn0_b, nullptr, 0, 0, 0, o.hbuf, DDP_FFN, M, DDP_FFN, 256, 1, st));
+    DDP_TRY(launch_linear(o.q1, 256, lw.ffn0_w, 256, lw.ffn0_b, nullptr, 0, 0, 0, o.hbuf, DDP_FFN, M, DDP_FFN, 256, 1, st, TAG_FC1));
     const float* fl = (film && lw.time_w) ? film + size_t(l) * 512 : nullptr;
     DDP_TRY(launch_linear_res_ln(o.hbuf, DDP_FFN, lw.ffn1_w, DDP_FFN, lw.ffn1_b, o.q1, 256, lw.norm1_w, lw.norm1_b, fl,
-                                 o.q, 256, M, DDP_FFN, st));
+                                 o.q, 256, M, DDP_FFN, st, TAG_FC2_LN));
   }
   return DDP_OK;
 }
@@ -282,6 +303,42 @@ extern "C" {
 
 const char* ddp_last_error(void) { return g_err; }
 int ddp_abi_version(void) { return DDP_ABI_VERSION; }
+
+int ddp_profile_begin(int tag) {
+  if (tag < 0 || tag >= TAG_COUNT) {
+    set_error("profile: unknown tag %d", tag);
+    return DDP_E_BADCFG;
+  }
+  if (!g_prof.created) {
+    for (int i = 0; i < 2 * PROF_MAX; ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) {
+        set_error("hipEventCreate failed");
+        return DDP_E_LAUNCH;
+      }
+    g_prof.created = true;
+  }
+  g_prof.n = 0;
+  g_prof.tag = tag;
+  return DDP_OK;
+}
+
+int ddp_profile_end(float* total_ms, int* launches) {
+  const int n = g_prof.n;
+  g_prof.tag = -1;
+  float tot = 0.f;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) {
+      set_error("hipEventSynchronize failed");
+      return DDP_E_LAUNCH;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return DDP_OK;
+}
 
 int ddp_query_workspace(const ddp_cfg* cfg, size_t* bytes) {
   DDP_TRY(validate(cfg));
@@ -337,7 +394,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
   DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
   DDP_TRY(launch_linear(o.xtok, o.Cx, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256,
-                        o.Cx, 0, st));
+                        o.Cx, 0, st, TAG_XPROJ));
   if (cfg->task == DDP_TASK_DEPTH) {
     if (hipMemcpyAsync(o.mask, d_noise, size_t(M0) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("noise copy failed");
@@ -355,13 +412,13 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.q, o.B, o.r, o.N, st));
     } else {
       float* dst = cfg->task == DDP_TASK_BEV ? o.feat0 : o.q;
-      DDP_TRY(launch_linear(o.mask, 256, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, dst, 256, M0, 256, 256, 0, st));
+      DDP_TRY(launch_linear(o.mask, 256, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, dst, 256, M0, 256, 256, 0, st, TAG_FEAT));
       if (cfg->task == DDP_TASK_BEV) DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, geom, st));
     }
     DDP_TRY(encoder_forward(weights, o, film, st));
     if (cfg->task == DDP_TASK_SEG) {
       DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
-                            256, 0, st));
+                            256, 0, st, TAG_HEAD));
       SegUpdateArgs a;
       a.logits = o.logits;
       a.ldl = o.ldl;
@@ -458,7 +515,7 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
   DDP_TRY(encoder_forward(weights, o, film, st));
   if (cfg->task == DDP_TASK_SEG) {
     DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256,
-                          0, st));
+                          0, st, TAG_HEAD));
     DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.R, 1, o.Nh, o.Kc, 1.0f, st));
   } else if (cfg->task == DDP_TASK_DEPTH) {
     DDP_TRY(launch_linear(o.q, 256, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st));

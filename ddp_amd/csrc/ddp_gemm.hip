@@ -6,7 +6,7 @@ namespace ddp {
 
 namespace {
 
-template <int NT, class Epi>
+template <int NT, int TAG, class Epi>
 int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const Epi& epi,
                 hipStream_t st) {
   if (M <= 0) return DDP_OK;
@@ -18,12 +18,14 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, 
   const size_t lds = gemm_lds_bytes<NT>();
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, Epi>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, Epi, TAG>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_gemm_tok<NT, Epi>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS), lds, st, A, lda,
+  prof_begin(TAG, st);
+  hipLaunchKernelGGL((k_gemm_tok<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS), lds, st, A, lda,
                      W, ldw, M, N, K, n_tiles_n, epi);
+  prof_end(TAG, st);
   return check_launch("k_gemm_tok");
 }
 
@@ -31,7 +33,7 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, 
 
 int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
                   int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
-                  hipStream_t st) {
+                  hipStream_t st, int tag) {
   EpiBias e;
   e.bias = bias;
   e.add = add;
@@ -46,15 +48,29 @@ int launch_linear(const float* A, int lda, const float* W, int ldw, const float*
     set_error("linear: N=%d, ldo=%d must be a multiple of 4", N, ldo);
     return DDP_E_BADCFG;
   }
-  if (N <= 32) return launch_gemm<1>(A, lda, W, ldw, M, N, K, e, st);
-  if (N <= 96) return launch_gemm<3>(A, lda, W, ldw, M, N, K, e, st);
-  if (N <= 160) return launch_gemm<5>(A, lda, W, ldw, M, N, K, e, st);
-  return launch_gemm<8>(A, lda, W, ldw, M, N, K, e, st);
+  if (N > 160) {
+    switch (tag) {
+      case TAG_XPROJ: return launch_gemm<8, TAG_XPROJ>(A, lda, W, ldw, M, N, K, e, st);
+      case TAG_FEAT: return launch_gemm<8, TAG_FEAT>(A, lda, W, ldw, M, N, K, e, st);
+      case TAG_VALUE: return launch_gemm<8, TAG_VALUE>(A, lda, W, ldw, M, N, K, e, st);
+      case TAG_FC1: return launch_gemm<8, TAG_FC1>(A, lda, W, ldw, M, N, K, e, st);
+      case TAG_HEAD: return launch_gemm<8, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
+      default: return launch_gemm<8, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
+    }
+  }
+  if (tag == TAG_HEAD) {
+    if (N <= 32) return launch_gemm<1, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
+    if (N <= 96) return launch_gemm<3, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
+    return launch_gemm<5, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
+  }
+  if (N <= 32) return launch_gemm<1, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
+  if (N <= 96) return launch_gemm<3, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
+  return launch_gemm<5, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
 }
 
 int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
                          const float* res, int ldres, const float* gamma, const float* beta,
-                         const float* film, float* out, int ldo, int M, int K, hipStream_t st) {
+                         const float* film, float* out, int ldo, int M, int K, hipStream_t st, int tag) {
   EpiResLN e;
   e.bias = bias;
   e.res = res;
@@ -64,7 +80,8 @@ int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const
   e.film = film;
   e.out = out;
   e.ldo = ldo;
-  return launch_gemm<8>(A, lda, W, ldw, M, 256, K, e, st);
+  if (tag == TAG_FC2_LN) return launch_gemm<8, TAG_FC2_LN>(A, lda, W, ldw, M, 256, K, e, st);
+  return launch_gemm<8, TAG_OUTPROJ_LN>(A, lda, W, ldw, M, 256, K, e, st);
 }
 
 int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
@@ -75,7 +92,7 @@ int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* 
   e.n_tok = n_tok;
   e.w = w;
   e.out = out;
-  return launch_gemm<3>(A, lda, Wcat, 256, M, 96, 256, e, st);
+  return launch_gemm<3, TAG_SAMP>(A, lda, Wcat, 256, M, 96, 256, e, st);
 }
 
 }  // namespace ddp

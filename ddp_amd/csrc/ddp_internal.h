@@ -9,15 +9,25 @@ namespace ddp {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// call-site tags of the GEMM launches (distinct kernel symbols for rocprofv3; profiler hook ids)
+enum GemmTag {
+  TAG_GENERIC = 0, TAG_XPROJ = 1, TAG_FEAT = 2, TAG_VALUE = 3, TAG_SAMP = 4, TAG_OUTPROJ_LN = 5, TAG_FC1 = 6,
+  TAG_FC2_LN = 7, TAG_HEAD = 8, TAG_COUNT = 9
+};
+// optional per-call-site event timing (ddp_profile_* in the C ABI); no-ops unless armed
+void prof_begin(int tag, hipStream_t st);
+void prof_end(int tag, hipStream_t st);
+
 // ---- ddp_gemm.hip -------------------------------------------------------------------------------
 // out = A W^T + bias (+ add[row map]) (+GELU);  A (M,K) lda, W (N,K) ldw; K % 32 == 0, N <= any.
 int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
                   int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
-                  hipStream_t st);
+                  hipStream_t st, int tag = TAG_GENERIC);
 // out = LN(A W^T + bias + res) * gamma + beta [ * (scale+1) + shift ];  N == 256
 int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
                          const float* res, int ldres, const float* gamma, const float* beta,
-                         const float* film, float* out, int ldo, int M, int K, hipStream_t st);
+                         const float* film, float* out, int ldo, int M, int K, hipStream_t st,
+                         int tag = TAG_OUTPROJ_LN);
 // samp = epilogue(A Wcat^T) with positional tables; Wcat (96,256)
 int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
                        int n_tok, int w, float* out, int M, hipStream_t st);

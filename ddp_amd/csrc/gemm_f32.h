@@ -53,7 +53,8 @@ struct LaneCtx {
 
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-template <int NT, class Epi>
+// TAG only names the call site (value_proj, fc1, ...) so that rocprofv3 reports each separately.
+template <int NT, class Epi, int TAG>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 k_gemm_tok(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int M, int N, int K,
            int n_tiles_n, Epi epi) {

@@ -70,10 +70,10 @@ class PackedWeights:
             n = state_dict[k].numel()
             offs[(l, f)] = (total, k)
             total += (n + 63) // 64 * 64
-        flat = torch.zeros(total, dtype=torch.float32)
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
         for (l, f), (o, k) in offs.items():
-            flat[o:o + state_dict[k].numel()] = state_dict[k].detach().reshape(-1).to(torch.float32).cpu()
-        self.flat = flat.to(device)
+            flat[o:o + state_dict[k].numel()].copy_(state_dict[k].detach().reshape(-1))
+        self.flat = flat
         self.offsets = offs
         self.task = task
         self.num_layers = num_layers

@@ -1,0 +1,184 @@
+"""Drop-in ``DDP`` segmentor (plugin surface #1) for MMSegmentation-style configs.
+
+Keeps the constructor kwargs, attribute names, ``state_dict`` keys and the inference methods of
+segmentation/mmseg/models/segmentors/ddp.py:49-290 (``extract_feat``, ``encode_decode``,
+``ddim_sample``, ``ddpm_sample``, ``_decode_head_forward_test``, ``_get_sampling_timesteps``) while
+the K-step loop itself runs in libddp_mi355x.so through ``DDPEngine``.  Unlike the reference, whose
+sampler only works for one image per call (ddp.py:219-223 allocates the noisy map with batch
+``randsteps``), ``ddim_sample`` accepts b >= 1 images and draws independent noise for each.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import schedule
+from ..registry import SEGMENTORS, build_backbone, build_head, build_neck
+
+
+class LearnedSinusoidalPosEmb(nn.Module):
+    """parameter holder for time_mlp.0 (ddp.py:31-46); evaluated on device by k_sinusoid."""
+
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class _Conv1x1(nn.Module):
+    """``ConvModule(cin, cout, 1, norm_cfg=None, act_cfg=None)`` parameter holder: key ``conv.*``."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1)
+
+
+def _build_neck(neck):
+    if neck is None:
+        return None
+    if isinstance(neck, (list, tuple)):      # the DDP configs chain FPN -> MultiStageMerging
+        return nn.Sequential(*[build_neck(n) for n in neck])
+    return build_neck(neck)
+
+
+class _SamplerMixin:
+    """engine cache shared by the task variants."""
+
+    def _weights_version(self):
+        return sum(p._version for p in self.parameters())
+
+    def _get_engine(self, key, factory):
+        cache = self.__dict__.setdefault('_engine_cache', {})
+        key = key + (self._weights_version(),)
+        eng = cache.get(key)
+        if eng is None:
+            cache.clear()
+            eng = factory()
+            cache[key] = eng
+        return eng
+
+
+@SEGMENTORS.register_module()
+class DDP(nn.Module, _SamplerMixin):
+    task = 'seg'
+
+    def __init__(self, bit_scale=0.1, timesteps=1, randsteps=1, time_difference=1, learned_sinusoidal_dim=16,
+                 sample_range=(0, 0.999), noise_schedule='cosine', diffusion='ddim', accumulation=False,
+                 backbone=None, neck=None, decode_head=None, auxiliary_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__()
+        if noise_schedule not in schedule.NOISE_SCHEDULES:
+            raise ValueError(f'invalid noise schedule {noise_schedule}')            # ddp.py:90
+        if learned_sinusoidal_dim != 16:
+            raise ValueError('libddp_mi355x is built for learned_sinusoidal_dim=16')
+        self.backbone = build_backbone(backbone) if backbone is not None else None
+        self.neck = _build_neck(neck)
+        self.decode_head = build_head(decode_head)
+        self.auxiliary_head = None           # training-only deep supervision: out of scope
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bit_scale, self.timesteps, self.randsteps = bit_scale, timesteps, randsteps
+        self.diffusion, self.time_difference = diffusion, time_difference
+        self.sample_range, self.noise_schedule = sample_range, noise_schedule
+        self.use_gt = False
+        self.accumulation = accumulation
+        c = self.decode_head.in_channels[0]
+        self.embedding_table = nn.Embedding(self.num_classes + 1, c)
+        self.transform = _Conv1x1(c * 2, c)
+        time_dim = c * 4
+        self.time_mlp = nn.Sequential(LearnedSinusoidalPosEmb(learned_sinusoidal_dim),
+                                      nn.Linear(learned_sinusoidal_dim + 1, time_dim), nn.GELU(),
+                                      nn.Linear(time_dim, time_dim))
+
+    # -- plugin surface ------------------------------------------------------------------------
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def _get_sampling_timesteps(self, batch, *, device):
+        times = []
+        for t_now, t_next in schedule.get_sampling_timesteps(self.timesteps, self.time_difference,
+                                                             self.sample_range[0]):
+            t = torch.tensor([t_now, t_next], device=device)
+            times.append(t[:, None].repeat(1, batch))
+        return times
+
+    def _engine_for(self, b, h, w, device, sampler):
+        def factory():
+            from ..engine import DDPEngine
+            return DDPEngine(self.hot_path_state_dict(), 'seg', h=h, w=w, batch=b, randsteps=self.randsteps,
+                             timesteps=self.timesteps, num_classes=self.num_classes, feat_channels=256,
+                             bit_scale=self.bit_scale, time_difference=self.time_difference,
+                             sample_range0=self.sample_range[0], noise_schedule=self.noise_schedule,
+                             sampler=sampler, accumulation=self.accumulation, device=device)
+        return self._get_engine((b, h, w, str(device), sampler, self.timesteps, self.randsteps, self.accumulation,
+                                 self.bit_scale), factory)
+
+    def hot_path_state_dict(self):
+        return {k: v for k, v in self.state_dict().items()
+                if not k.startswith(('backbone.', 'neck.', 'auxiliary_head.'))}
+
+    def _check_feature(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('ddp_amd has no CPU path: features must live on an MI355X (HIP) device')
+        if x.shape[1] != self.decode_head.in_channels[0]:
+            raise RuntimeError(f'expected {self.decode_head.in_channels[0]} feature channels, got {x.shape[1]}')
+
+    @torch.no_grad()
+    def ddim_sample(self, x, img_metas=None, noise=None):
+        """x (b,256,h,w) -> (b,K,h,w).  ``noise`` (b,r,256,h,w) may be injected (parity tests);
+        by default it is drawn with torch.randn like the reference (ddp.py:220)."""
+        self._check_feature(x)
+        b, c, h, w = x.shape
+        if noise is None:
+            noise = torch.randn((b, self.randsteps, c, h, w), device=x.device)
+        eng = self._engine_for(b, h, w, x.device, 'ddim')
+        return eng.sample(x.contiguous().float(), noise.contiguous().float())
+
+    @torch.no_grad()
+    def ddpm_sample(self, x, img_metas=None, noise=None, step_noise=None):
+        self._check_feature(x)
+        b, c, h, w = x.shape
+        if noise is None:
+            noise = torch.randn((b, self.randsteps, c, h, w), device=x.device)
+        if step_noise is None:
+            step_noise = torch.randn((self.timesteps, b, self.randsteps, c, h, w), device=x.device)
+        eng = self._engine_for(b, h, w, x.device, 'ddpm')
+        return eng.sample(x.contiguous().float(), noise.contiguous().float(), step_noise.contiguous().float())
+
+    def _decode_head_forward_test(self, x, t, img_metas=None):
+        return self.decode_head.forward_test(x, t, img_metas, self.test_cfg)
+
+    def encode_decode(self, img, img_metas=None):
+        """ddp.py:114-129."""
+        x = self.extract_feat(img)[0]
+        if self.diffusion == 'ddim':
+            out = self.ddim_sample(x, img_metas)
+        elif self.diffusion == 'ddpm':
+            out = self.ddpm_sample(x, img_metas)
+        else:
+            raise NotImplementedError
+        return F.interpolate(out, size=img.shape[2:], mode='bilinear', align_corners=self.align_corners)
+
+    def whole_inference(self, img, img_meta=None, rescale=False):
+        return self.encode_decode(img, img_meta)
+
+    def simple_test(self, img, img_meta=None, rescale=True):
+        seg_logit = F.softmax(self.encode_decode(img, img_meta), dim=1)       # encoder_decoder.py:277
+        return list(seg_logit.argmax(dim=1).cpu().numpy())
+
+    def forward(self, img, img_metas=None, return_loss=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
+        if isinstance(img, (list, tuple)):
+            img = img[0]
+        return self.simple_test(img, img_metas)
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')

@@ -156,6 +156,13 @@ int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time
 int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, const float* d_lut,
                         float* d_mask, int rows, const ddp_step* step, void* stream);
 
+/* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
+ * around every launch of one GEMM call site, then read the summed duration and launch count.
+ * tag: 1 xproj, 2 feat, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN,
+ * 8 head conv.  ddp_profile_end synchronises on the recorded events. */
+int ddp_profile_begin(int tag);
+int ddp_profile_end(float* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

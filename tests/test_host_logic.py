@@ -1,0 +1,167 @@
+"""CPU tests: host-side logic (schedule, plugin surface, state_dict layout, C-ABI exports, error
+behaviour).  No GPU compute is invoked."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import ddp_amd
+from ddp_amd import _lib, schedule
+from ddp_amd.engine import PackedWeights, hot_path_keys
+from ddp_amd.utils import synthetic
+from oracle import ddp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ENCODER = dict(type='DetrTransformerEncoder', num_layers=6,
+               transformerlayers=dict(type='BaseTransformerLayer', use_time_mlp=True,
+                                      attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256,
+                                                     num_levels=1, num_heads=8, dropout=0.),
+                                      ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024,
+                                                    ffn_drop=0., act_cfg=dict(type='GELU')),
+                                      operation_order=('self_attn', 'norm', 'ffn', 'norm')))
+POSENC = dict(type='SinePositionalEncoding', num_feats=128, normalize=True, offset=-0.5)
+
+
+def seg_cfg(**over):
+    # model dict of segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py:11-108 (hot-path part)
+    cfg = dict(type='DDP', timesteps=3, bit_scale=0.01, accumulation=True,
+               decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
+                                dropout_ratio=0., num_classes=150, norm_cfg=dict(type='SyncBN'), align_corners=False,
+                                num_feature_levels=1, encoder=ENCODER, positional_encoding=POSENC,
+                                loss_decode=dict(type='CrossEntropyLoss')),
+               train_cfg=dict(), test_cfg=dict(mode='whole'))
+    cfg.update(over)
+    return cfg
+
+
+def test_exports_match_header():
+    """every function declared in include/ddp_mi355x.h is exported by the built library."""
+    hdr = open(os.path.join(ROOT, 'include', 'ddp_mi355x.h')).read()
+    names = set(re.findall(r'^\s*(?:const char\*|int)\s+(ddp_\w+)\s*\(', hdr, flags=re.M))
+    assert {'ddp_sample', 'ddp_prepare', 'ddp_query_workspace', 'ddp_head_forward', 'ddp_msda_forward',
+            'ddp_linear', 'ddp_time_embed', 'ddp_ddim_update_seg', 'ddp_last_error'} <= names
+    lib = ctypes.CDLL(_lib.lib_path())
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(_lib.EXPORTS) == names
+
+
+def test_cfg_validation_without_gpu():
+    """ddp_query_workspace validates on the host: usable without a device."""
+    lib = _lib.load()
+    cfg = _lib.DdpCfg()
+    cfg.abi_version = _lib.ABI_VERSION
+    cfg.task, cfg.batch, cfg.randsteps, cfg.timesteps, cfg.num_layers = 0, 8, 1, 3, 6
+    cfg.num_classes, cfg.feat_channels, cfg.h, cfg.w, cfg.head_h, cfg.head_w = 150, 256, 128, 256, 128, 256
+    n = ctypes.c_size_t(0)
+    assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(n)) == 0
+    assert 3e9 < n.value < 5e9           # C2: ~3.4 GB of activations for 8 images
+    cfg.timesteps = 1000
+    assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(n)) == -1
+    assert b'timesteps' in lib.ddp_last_error()
+    cfg.timesteps, cfg.abi_version = 3, 99
+    assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(n)) == -1
+    cfg.abi_version, cfg.feat_channels = _lib.ABI_VERSION, 100
+    assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(n)) == -1
+    cfg.feat_channels, cfg.sampler, cfg.task = 256, 1, 1      # ddpm is defined for seg only
+    assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(n)) == -1
+
+
+@pytest.mark.parametrize('K,td,sr0,sched', [(1, 1, 0.0, 'cosine'), (3, 1, 0.0, 'cosine'), (10, 1, 0.0, 'cosine'),
+                                            (4, 1, 0.1, 'linear'), (5, 0, 0.0, 'cosine')])
+def test_schedule_matches_oracle(K, td, sr0, sched):
+    recs = schedule.step_records('seg', K, td, sr0, sched, 'ddpm')
+    fn = O.alpha_cosine_log_snr if sched == 'cosine' else O.beta_linear_log_snr
+    for r, (tn, tx) in zip(recs, O.sampling_time_pairs(K, td, sr0)):
+        ls, lsn = fn(torch.tensor([tn])), fn(torch.tensor([tx]))
+        a, s = O.log_snr_to_alpha_sigma(ls)
+        an, sn = O.log_snr_to_alpha_sigma(lsn)
+        assert r['time_in'] == float(ls) and r['alpha'] == float(a) and r['sigma'] == float(s)
+        assert r['alpha_next'] == float(an) and r['sigma_next'] == float(sn)
+        c = -torch.special.expm1(ls - lsn)
+        assert r['ddpm_c'] == float(c) and r['ddpm_add_noise'] == int(tx > 0)
+
+
+def test_schedule_depth_and_bad_name():
+    recs = schedule.step_records('depth', 20)
+    assert recs[0]['time_in'] == 1.0 and abs(recs[0]['alpha'] - 7.8396e-05) < 1e-8
+    assert recs[-1]['alpha_next'] > 0.9999
+    with pytest.raises(ValueError):
+        schedule.step_records('seg', 3, noise_schedule='sigmoid')
+
+
+def test_build_segmentor_and_state_dict_layout():
+    """the registered drop-in accepts the reference config dict and exposes exactly the reference's
+    hot-path state_dict keys/shapes (8 522 462 parameters)."""
+    model = ddp_amd.build_segmentor(seg_cfg())
+    assert type(model).__name__ == 'DDP' and type(model.decode_head).__name__ == 'DeformableHeadWithTime'
+    sd = synthetic.make_state_dict('seg', 150, 6, 256, seed=0)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    assert sum(p.numel() for p in model.parameters()) == 8522462
+    model.load_state_dict(sd, strict=True)
+    assert model.num_classes == 150 and model.align_corners is False and model.decode_head.in_channels[0] == 256
+    tp = model._get_sampling_timesteps(1, device='cpu')
+    assert len(tp) == 3 and tp[0].shape == (2, 1) and float(tp[0][0]) == 1.0 and abs(float(tp[0][1]) - 1 / 3) < 1e-6
+
+
+def test_depth_and_bev_state_dict_layout():
+    cfg = dict(type='DDP', sample_range=(0., 0.999), bit_scale=0.1, timesteps=3, min_depth=1e-3, max_depth=80,
+               decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
+                                dropout_ratio=0., n_bins=None, scale_up=False, init_inputs=True, min_depth=1e-3,
+                                max_depth=80, use_eps=True, align_corners=False, num_feature_levels=1,
+                                encoder=ENCODER, positional_encoding=POSENC))
+    m = ddp_amd.build_depther(cfg)
+    sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=0)
+    m.load_state_dict(sd, strict=True)
+    head = ddp_amd.BEVDeformableHeadWithTime(
+        num_feature_levels=1, encoder=dict(ENCODER, num_layers=5), positional_encoding=POSENC,
+        classes=list('abcdef'), loss='focal',
+        grid_transform=dict(input_scope=[[-51.2, 51.2, 0.8]] * 2, output_scope=[[-50, 50, 0.5]] * 2))
+    bev = ddp_amd.BEVDDP(bit_scale=0.01, timesteps=3, randsteps=2, feat_channels=512)
+    sdb = synthetic.make_state_dict('bev', 6, 5, 512, seed=0)
+    bev.load_state_dict({k: v for k, v in sdb.items() if not k.startswith('decode_head.')}, strict=True)
+    head.load_state_dict({k[len('decode_head.'):]: v for k, v in sdb.items() if k.startswith('decode_head.')}, strict=True)
+
+
+def test_error_behaviour_matches_reference():
+    with pytest.raises(ValueError, match='invalid noise schedule'):          # segmentors/ddp.py:90
+        ddp_amd.build_segmentor(seg_cfg(noise_schedule='sigmoid'))
+    model = ddp_amd.build_segmentor(seg_cfg(diffusion='plms'))
+    model.backbone = lambda img: [torch.zeros(1, 256, 4, 4)]
+    with pytest.raises(NotImplementedError):                                 # segmentors/ddp.py:123
+        model.encode_decode(torch.zeros(1, 3, 16, 16))
+    model = ddp_amd.build_segmentor(seg_cfg())
+    with pytest.raises(RuntimeError, match='no CPU path'):                   # product never falls back to CPU
+        model.ddim_sample(torch.zeros(1, 256, 4, 4))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model.decode_head.forward([torch.zeros(1, 256, 4, 4)], torch.zeros(1, 1024))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ddp_amd import build as b
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(b, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.DdpError, match='no non-HIP fallback'):
+        _lib.load()
+
+
+def test_packed_weights_table():
+    """one flat blob, 256-byte aligned sub-tensors, pointer table consistent with the key map."""
+    sd = synthetic.make_state_dict('seg', 19, 2, 256, seed=3)
+    pw = PackedWeights(sd, 'seg', 2, 'cpu')
+    base = pw.flat.data_ptr()
+    top, layers = hot_path_keys('seg', 2)
+    for f, k in top:
+        off, key = pw.offsets[(None, f)]
+        assert key == k and off % 64 == 0 and getattr(pw.struct, f) == base + 4 * off
+        assert torch.equal(pw.flat[off:off + sd[k].numel()], sd[k].reshape(-1))
+    for l, lk in enumerate(layers):
+        for f, k in lk:
+            off, _ = pw.offsets[(l, f)]
+            assert getattr(pw.struct.layers[l], f) == base + 4 * off
+    assert pw.struct.layers[2].value_proj_w is None          # unused layer slots stay NULL
+    with pytest.raises(KeyError):
+        PackedWeights({k: v for k, v in sd.items() if 'value_proj.weight' not in k}, 'seg', 2, 'cpu')

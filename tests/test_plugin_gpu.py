@@ -1,0 +1,113 @@
+"""The registered drop-in classes (plugin surface) on the GPU: same configs / state_dict / methods as the
+reference classes, outputs equal to the golden vectors recorded from the reference."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ddp_amd
+from golden_util import load_case, max_rel
+from test_host_logic import ENCODER, POSENC, seg_cfg
+
+pytestmark = pytest.mark.gpu
+REL = 2e-4
+
+
+class FakeBackbone(torch.nn.Module):
+    """stands in for Swin+FPN+MultiStageMerging (frozen, upstream of the hot path): returns [x]."""
+
+    def __init__(self, x):
+        super().__init__()
+        self.x = x
+
+    def forward(self, img):
+        return [self.x]
+
+
+def _seg_model(cfg):
+    model = ddp_amd.build_segmentor(seg_cfg(
+        timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'],
+        accumulation=cfg['accumulation'], noise_schedule=cfg['noise_schedule'], diffusion=cfg['diffusion'],
+        sample_range=tuple(cfg.get('sample_range', (0, 0.999))),
+        decode_head=dict(seg_cfg()['decode_head'], num_classes=cfg['num_classes'])))
+    return model
+
+
+@pytest.mark.parametrize('name', ['seg_ade_k3', 'seg_city_r2', 'seg_linear'])
+def test_segmentor_ddim_sample(name):
+    cfg, sd, x, noise, _, g = load_case(name)
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    out = model.ddim_sample(x.cuda(), None, noise=noise.unsqueeze(0).cuda())
+    assert max_rel(out.cpu(), g['out']) < REL
+    # encode_decode: extract_feat -> loop -> bilinear resize to the image size (segmentors/ddp.py:114-129)
+    model.backbone = FakeBackbone(x.cuda())
+    img = torch.zeros(1, 3, cfg['h'] * 4, cfg['w'] * 4, device='cuda')
+    torch.manual_seed(0)
+    o1 = model.encode_decode(img, None)
+    torch.manual_seed(0)
+    o2 = model.encode_decode(img, None)
+    assert o1.shape == (1, cfg['num_classes'], cfg['h'] * 4, cfg['w'] * 4)
+    assert torch.equal(o1, o2)                       # same seed -> bit-identical, like the reference
+    labels = model.simple_test(img, None)
+    assert labels[0].shape == (cfg['h'] * 4, cfg['w'] * 4)
+
+
+def test_segmentor_ddpm_sample():
+    cfg, sd, x, noise, step_noise, g = load_case('seg_ddpm')
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    out = model.ddpm_sample(x.cuda(), None, noise=noise.unsqueeze(0).cuda(), step_noise=step_noise.unsqueeze(1).cuda())
+    assert max_rel(out.cpu(), g['out']) < REL
+
+
+def test_decode_head_forward_surface():
+    """DeformableHeadWithTime.forward(inputs, times) called the way DDP._decode_head_forward_test does."""
+    from oracle import ddp_oracle as O
+    cfg, sd, x, noise, _, g = load_case('seg_city_r2')
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    temb = O.time_mlp(O.alpha_cosine_log_snr(torch.tensor([1.0])), sd).cuda()
+    logits = model._decode_head_forward_test([g['feat_step0'].cuda()], temb, img_metas=None)
+    assert logits.shape == g['logits_steps'][0].shape
+    assert max_rel(logits.cpu(), g['logits_steps'][0]) < REL
+    # changing a parameter in place invalidates the cached engine
+    with torch.no_grad():
+        model.decode_head.conv_seg.bias.add_(1.0)
+    logits2 = model._decode_head_forward_test([g['feat_step0'].cuda()], temb, img_metas=None)
+    assert max_rel(logits2.cpu(), g['logits_steps'][0] + 1.0) < REL
+
+
+def test_depther_sample():
+    cfg, sd, x, noise, _, g = load_case('depth_k3_r2')
+    dcfg = dict(type='DDP', bit_scale=cfg['bit_scale'], timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                min_depth=cfg['min_depth'], max_depth=cfg['max_depth'],
+                decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
+                                 dropout_ratio=0., scale_up=False, min_depth=1e-3, max_depth=80, use_eps=True,
+                                 align_corners=False, num_feature_levels=1, encoder=ENCODER, positional_encoding=POSENC))
+    model = ddp_amd.build_depther(dcfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    out = model.sample(x.cuda(), None, noise=noise.unsqueeze(0).cuda())
+    assert max_rel(out.cpu(), g['out']) < REL
+    model.backbone = FakeBackbone(x.cuda())
+    o = model.encode_decode(torch.zeros(1, 3, cfg['h'] * 4, cfg['w'] * 4, device='cuda'), None, rescale=True)
+    assert o.shape == (1, 1, cfg['h'] * 4, cfg['w'] * 4) and float(o.min()) >= 1e-3 and float(o.max()) <= 80
+
+
+def test_bev_ddim_sample():
+    cfg, sd, x, noise, _, g = load_case('bev_fusion')
+    head = ddp_amd.BEVDeformableHeadWithTime(
+        num_feature_levels=1, encoder=dict(ENCODER, num_layers=cfg['num_layers']), positional_encoding=POSENC,
+        classes=list('abcdef'), loss='focal',
+        grid_transform=dict(input_scope=cfg['input_scope'], output_scope=cfg['output_scope']))
+    model = ddp_amd.BEVDDP(bit_scale=cfg['bit_scale'], timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                           feat_channels=cfg['feat_channels'])
+    model.load_state_dict({k: v for k, v in sd.items() if not k.startswith('decode_head.')}, strict=True)
+    head.load_state_dict({k[len('decode_head.'):]: v for k, v in sd.items() if k.startswith('decode_head.')}, strict=True)
+    model, head = model.cuda().eval(), head.cuda().eval()
+    out = model.ddim_sample([x.cuda()], head, noise=noise.unsqueeze(0).cuda())
+    assert out.shape == g['out'].shape
+    assert max_rel(out.cpu(), g['out']) < REL
