@@ -170,8 +170,8 @@ def main():
         cpu = dict(value=round(n_img / tcpu, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
                    sample=f'{n_img} x (1x512x1024, {K}-step DDIM, 150 classes) of the same synthetic workload, '
                           f'torch CPU fp32 oracle, {tcpu:.1f} s')
-        parity = dict(max_rel_vs_oracle=worst, argmax_agreement=agree, images_checked=n_img,
-                      pixels_above_1e-4=bad_px, gate=1e-3)
+        parity = {'max_rel_vs_oracle': worst, 'argmax_agreement': agree, 'images_checked': n_img,
+                  'pixels_above_1e-4': bad_px, 'gate': 1e-3}
 
     if rank == 0:
         line = {
