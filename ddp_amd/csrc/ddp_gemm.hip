@@ -1,8 +1,12 @@
 // ddp_gemm.hip - instantiations / launchers of the fp32-MFMA token GEMM (gemm_f32.h).
+#include <stdlib.h>
+
 #include "ddp_internal.h"
 #include "gemm_f32.h"
 
 namespace ddp {
+
+unsigned long long* g_gemm_dbg = nullptr;   // probe: per-block cycle stamps (ddp_debug_set_stamps)
 
 namespace {
 
@@ -15,16 +19,39 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, 
     return DDP_E_BADCFG;
   }
   const int n_tiles_n = (N + NT * 32 - 1) / (NT * 32);
-  const size_t lds = gemm_lds_bytes<NT>();
+  static int variant = -1;        // DDP_GEMM_V=1 selects the LDS-staged-A main loop (A/B experiments)
+  if (variant < 0) {
+    const char* e = getenv("DDP_GEMM_V");
+    variant = e ? atoi(e) : 2;
+  }
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, Epi, TAG>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(gemm_lds_bytes<NT>()));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok2<NT, Epi, TAG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(gemm2_lds_bytes<NT>()));
     attr_done = true;
   }
   prof_begin(TAG, st);
-  hipLaunchKernelGGL((k_gemm_tok<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS), lds, st, A, lda,
-                     W, ldw, M, N, K, n_tiles_n, epi);
+  {
+    static int stagger_mul = -1;    // DDP_GEMM_STAGGER = sleeps (of 8128 cycles) per k-tile, x16; default 16 = 1 per k-tile
+    if (stagger_mul < 0) {
+      const char* e = getenv("DDP_GEMM_STAGGER");
+      stagger_mul = e ? atoi(e) : 16;
+    }
+    static int stagger_mode = -1;
+    if (stagger_mode < 0) {
+      const char* e = getenv("DDP_GEMM_STAGGER_MODE");
+      stagger_mode = e ? atoi(e) : 0;
+    }
+    const int stagger = stagger_mul < 0 ? stagger_mul : ((K / GEMM_BK) * stagger_mul / 16) | (stagger_mode << 16);
+    if (variant == 1 || (K % (2 * GEMM_BK)) != 0)
+      hipLaunchKernelGGL((k_gemm_tok<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS),
+                         gemm_lds_bytes<NT>(), st, A, lda, W, ldw, M, N, K, n_tiles_n, epi, stagger, g_gemm_dbg);
+    else
+      hipLaunchKernelGGL((k_gemm_tok2<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS),
+                         gemm2_lds_bytes<NT>(), st, A, lda, W, ldw, M, N, K, n_tiles_n, epi, stagger, g_gemm_dbg);
+  }
   prof_end(TAG, st);
   return check_launch("k_gemm_tok");
 }
@@ -96,3 +123,6 @@ int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* 
 }
 
 }  // namespace ddp
+
+extern "C" void ddp_debug_set_stamps(void* buf) { ddp::g_gemm_dbg = static_cast<unsigned long long*>(buf); }
+

@@ -1,28 +1,3 @@
-python - <<'PY'
-import torch, time, sys
-sys.path.insert(0,'.')
-from oracle import ddp_oracle as O
-from ddp_amd.utils import synthetic
-from ddp_amd.engine import DDPEngine
-torch.set_num_threads(16)
-dev=torch.device('cuda:0')
-sd = synthetic.make_state_dict('seg',150,6,256,seed=2)
-h,w=128,256
-x, noise = synthetic.make_inputs(1,h,w,1,256,256,seed=0)
-dx,dn=x.to(dev),noise.to(dev)
-for K,acc in ((1,False),(3,False),(3,True)):
-    eng = DDPEngine(sd,'seg',h=h,w=w,batch=1,timesteps=K,num_classes=150,bit_scale=0.01,accumulation=acc,device=dev)
-    out = eng.sample(dx,dn).cpu()
-    tr=[]
-    ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=K, bit_scale=0.01, accumulation=acc, trace=tr)
-    d=(out-ref).abs()
-    perpix = d.amax(1)[0]   # (h,w)
-    scale = ref.abs().max()
-    print(f'K={K} acc={acc}: max-rel {float(d.max()/scale):.3e}  median-pixel-rel {float(perpix.median()/scale):.3e}  99.9pct {float(perpix.flatten().kthvalue(int(0.999*h*w))[0]/scale):.3e}  pixels>1e-4: {int((perpix/scale>1e-4).sum())}  argmax agree {float((out.argmax(1)==ref.argmax(1)).float().mean()):.6f}')
-    if K==3 and not acc:
-        # near ties at intermediate steps of the oracle
-        for s,t in enumerate(tr):
-            top2 = t['logits'].topk(2,dim=1)[0]
-            gap = (top2[:,0]-top2[:,1])
-            print('  step',s,'min top-2 logit gap', float(gap.min()), 'pixels with gap<1e-4:', int((gap<1e-4).sum()))
-PY
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+for v in 2; do echo "== V=$v"; DDP_GEMM_STAGGER=0 DDP_GEMM_V=$v python scripts/gemm_probe.py 2>&1 | tail -7;  DDP_GEMM_STAGGER=0 DDP_GEMM_V=$v python scripts/gemm_probe3.py 2>&1 | tail -2 | cut -c1-250; done
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline'])"
