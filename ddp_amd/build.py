@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libddp_mi355x.so')
 SOURCES = ['ddp_api.hip', 'ddp_gemm.hip', 'ddp_kernels.hip']
 HEADERS = ['ddp_internal.h', 'gemm_f32.h', os.path.join('..', '..', 'include', 'ddp_mi355x.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
 def _hipcc():

@@ -76,7 +76,7 @@ struct Layout {
   size_t M0, M;   // tokens at (h,w) and at the head grid, over all B*r maps
   int ldl;        // row stride of logits / prob buffers
   // constants
-  float *tin, *u, *hid, *temb, *film, *lut, *wx, *wm, *wtap;
+  float *tin, *u, *hid, *temb, *film, *aff, *lut, *wx, *wm, *wtap;
   float *wcat[DDP_MAX_LAYERS], *bcat[DDP_MAX_LAYERS], *py[DDP_MAX_LAYERS], *px[DDP_MAX_LAYERS];
   // activations
   float *xproj, *mask, *pred, *feat0, *q, *q1, *v, *s, *samp, *hbuf, *logits, *prob, *snoise, *xtok;
@@ -161,6 +161,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->hid = cv.take(size_t(o->K) * DDP_TIME_DIM);
   o->temb = cv.take(size_t(o->K) * DDP_TIME_DIM);
   o->film = cv.take(size_t(o->K) * o->L * 512);
+  o->aff = cv.take(size_t(o->K) * o->L * 512);   // norms.1 affine x FiLM per (step, layer)
   o->lut = cv.take(size_t(o->Kc + 1) * 256);
   o->wx = cv.take(size_t(256) * o->Cx);
   o->wm = cv.take(size_t(256) * o->Cm);
@@ -177,12 +178,13 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
   o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
   o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
-  o->q = cv.take(o->M * 256);
-  o->q1 = cv.take(o->M * 256);
-  o->v = cv.take(o->M * 256);
-  o->s = cv.take(o->M * 256);
+  const size_t Mp = (o->M + 127) / 128 * 128;        // fragment-major buffers hold whole 128-token tiles
+  o->q = cv.take(Mp * 256);                          // fragment-major
+  o->q1 = cv.take(Mp * 256);                         // fragment-major
+  o->v = cv.take(o->M * 256);                        // row-major (gather taps want a head's 128 B contiguous)
+  o->s = cv.take(o->M * 256);                        // row-major
   o->samp = cv.take(o->M * DDP_SAMP_STRIDE);
-  size_t hb = o->M * DDP_FFN;
+  size_t hb = Mp * DDP_FFN;                          // fragment-major
   const size_t xt = size_t(o->B) * o->N * o->Cx;
   if (xt > hb) hb = xt;
   o->hbuf = cv.take(hb);
@@ -257,6 +259,22 @@ int time_embed_dev(const ddp_weights* w, int L, const float* tin, int S, float* 
   return DDP_OK;
 }
 
+// norms.1 affine folded with the per-(step,layer) FiLM vectors
+int fold_affine_dev(const ddp_weights* w, int L, int S, const float* film, float* aff, hipStream_t st) {
+  for (int l = 0; l < L; ++l) {
+    const ddp_layer_weights& lw = w->layers[l];
+    for (int s = 0; s < S; ++s) {
+      float* dst = aff + (size_t(s) * L + l) * 512;
+      if (lw.time_w && film) {
+        DDP_TRY(launch_fold_affine(lw.norm1_w, lw.norm1_b, film + (size_t(s) * L + l) * 512, dst, 1, st));
+      } else {
+        DDP_TRY(launch_pack_rows(lw.norm1_w, 1, lw.norm1_b, 1, dst, 256, st));
+      }
+    }
+  }
+  return DDP_OK;
+}
+
 // constants that do not depend on the schedule
 int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipStream_t st) {
   DDP_TRY(launch_pack_cols(w->transform_w, o.Cx + o.Cm, 0, 256, o.Cx, o.wx, st));
@@ -272,24 +290,25 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
   return DDP_OK;
 }
 
-// DetrTransformerEncoder over token-major q (in/out), FiLM vectors film (L,512) or nullptr
-int encoder_forward(const ddp_weights* w, const Layout& o, const float* film, hipStream_t st) {
+// DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
+int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st) {
   const int M = int(o.M);
   for (int l = 0; l < o.L; ++l) {
     const ddp_layer_weights& lw = w->layers[l];
     // value / sampling projections (multi_scale_deform_attn.py:313-328)
-    DDP_TRY(launch_linear(o.q, 256, lw.value_proj_w, 256, lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, 0, st, TAG_VALUE));
-    DDP_TRY(launch_linear_samp(o.q, 256, o.wcat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
+    DDP_TRY(launch_linear(o.q, 256, true, lw.value_proj_w, 256, lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, 0,
+                          st, TAG_VALUE));
+    DDP_TRY(launch_linear_samp(o.q, o.wcat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
     // bilinear gather + weighted sum (:94-151)
     DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
     // output_proj + identity, LayerNorm (:352-358; utils/transformer.py:390-392)
-    DDP_TRY(launch_linear_res_ln(o.s, 256, lw.output_proj_w, 256, lw.output_proj_b, o.q, 256, lw.norm0_w, lw.norm0_b,
-                                 nullptr, o.q1, 256, M, 256, st, TAG_OUTPROJ_LN));
+    DDP_TRY(launch_linear_res_ln_blk(o.s, 256, false, lw.output_proj_w, 256, lw.output_proj_b, o.q, lw.norm0_w, lw.norm0_b,
+                                     o.q1, M, 256, st));
     // FFN + identity, LayerNorm, FiLM (mmcv FFN :269-280; utils/transformer.py:413-417)
-    DDP_TRY(launch_linear(o.q1, 256, lw.ffn0_w, 256, lw.ffn0_b, nullptr, 0, 0, 0, o.hbuf, DDP_FFN, M, DDP_FFN, 256, 1, st, TAG_FC1));
-    const float* fl = (film && lw.time_w) ? film + size_t(l) * 512 : nullptr;
-    DDP_TRY(launch_linear_res_ln(o.hbuf, DDP_FFN, lw.ffn1_w, DDP_FFN, lw.ffn1_b, o.q1, 256, lw.norm1_w, lw.norm1_b, fl,
-                                 o.q, 256, M, DDP_FFN, st, TAG_FC2_LN));
+    DDP_TRY(launch_linear_blk(o.q1, 256, true, lw.ffn0_w, 256, lw.ffn0_b, nullptr, 0, 0, 0, o.hbuf, M, DDP_FFN, 256, 1, st));
+    const float* a = aff + size_t(l) * 512;
+    DDP_TRY(launch_linear_res_ln_blk(o.hbuf, DDP_FFN, true, lw.ffn1_w, DDP_FFN, lw.ffn1_b, o.q1, a, a + 256, o.q, M, DDP_FFN,
+                                     st));
   }
   return DDP_OK;
 }
@@ -369,6 +388,7 @@ int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* 
   for (int s = 0; s < o.K; ++s) tin[s] = steps[s].time_in;
   DDP_TRY(launch_write_floats(tin, o.K, o.tin, st));
   DDP_TRY(time_embed_dev(weights, o.L, o.tin, o.K, o.u, o.hid, o.temb, o.film, st));
+  DDP_TRY(fold_affine_dev(weights, o.L, o.K, o.film, o.aff, st));
   return DDP_OK;
 }
 
@@ -393,8 +413,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
 
   // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
   DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
-  DDP_TRY(launch_linear(o.xtok, o.Cx, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256,
-                        o.Cx, 0, st, TAG_XPROJ));
+  DDP_TRY(launch_linear(o.xtok, o.Cx, false, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N,
+                        256, o.Cx, 0, st, TAG_XPROJ));
   if (cfg->task == DDP_TASK_DEPTH) {
     if (hipMemcpyAsync(o.mask, d_noise, size_t(M0) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("noise copy failed");
@@ -406,19 +426,24 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
 
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
-    const float* film = o.film + size_t(s) * o.L * 512;
+    const float* aff = o.aff + size_t(s) * o.L * 512;
     // feat = transform(cat[x, mask_t])
     if (cfg->task == DDP_TASK_DEPTH) {
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.q, o.B, o.r, o.N, st));
     } else {
-      float* dst = cfg->task == DDP_TASK_BEV ? o.feat0 : o.q;
-      DDP_TRY(launch_linear(o.mask, 256, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, dst, 256, M0, 256, 256, 0, st, TAG_FEAT));
-      if (cfg->task == DDP_TASK_BEV) DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, geom, st));
+      if (cfg->task == DDP_TASK_BEV) {
+        DDP_TRY(launch_linear(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256,
+                              256, 0, st));
+        DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, geom, st));
+      } else {
+        DDP_TRY(launch_linear_blk(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q, M0, 256, 256, 0,
+                                  st));
+      }
     }
-    DDP_TRY(encoder_forward(weights, o, film, st));
+    DDP_TRY(encoder_forward(weights, o, aff, st));
     if (cfg->task == DDP_TASK_SEG) {
-      DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
-                            256, 0, st, TAG_HEAD));
+      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M,
+                            o.Kc, 256, 0, st, TAG_HEAD));
       SegUpdateArgs a;
       a.logits = o.logits;
       a.ldl = o.ldl;
@@ -437,7 +462,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       }
       DDP_TRY(launch_seg_update(a, st));
     } else if (cfg->task == DDP_TASK_DEPTH) {
-      DDP_TRY(launch_linear(o.q, 256, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st));
+      DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
       DepthUpdateArgs a;
       a.taps = o.logits;
       a.bias = 0.f;
@@ -454,8 +479,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       a.st = sp;
       DDP_TRY(launch_depth_update(a, st));
     } else {
-      DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256,
-                            0, st));
+      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc,
+                            256, 0, st, TAG_HEAD));
       BevUpdateArgs a;
       a.logits = o.logits;
       a.num_classes = o.Kc;
@@ -506,19 +531,21 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
     }
     film = o.film;
   }
+  DDP_TRY(fold_affine_dev(weights, o.L, 1, film, o.aff, st));
   if (cfg->task == DDP_TASK_BEV) {
     DDP_TRY(launch_nchw_to_tok(d_feat, o.feat0, o.R, 256, o.N, st));
     DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, bev_geom(cfg), st));
   } else {
-    DDP_TRY(launch_nchw_to_tok(d_feat, o.q, o.R, 256, o.N, st));
+    DDP_TRY(launch_nchw_to_tok(d_feat, o.s, o.R, 256, o.N, st));      // row-major staging in `s`
+    DDP_TRY(launch_row_to_blk(o.s, o.q, M, st));
   }
-  DDP_TRY(encoder_forward(weights, o, film, st));
+  DDP_TRY(encoder_forward(weights, o, o.aff, st));
   if (cfg->task == DDP_TASK_SEG) {
-    DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256,
-                          0, st, TAG_HEAD));
+    DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
+                          256, 0, st, TAG_HEAD));
     DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.R, 1, o.Nh, o.Kc, 1.0f, st));
   } else if (cfg->task == DDP_TASK_DEPTH) {
-    DDP_TRY(launch_linear(o.q, 256, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st));
+    DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
     DepthUpdateArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = o.logits;
@@ -534,8 +561,8 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
     a.eps_depth = cfg->min_depth;
     DDP_TRY(launch_depth_update(a, st));
   } else {
-    DDP_TRY(launch_linear(o.q, 256, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256, 0,
-                          st));
+    DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256,
+                          0, st, TAG_HEAD));
     BevUpdateArgs a;
     memset(&a, 0, sizeof(a));
     a.logits = o.logits;
@@ -574,7 +601,8 @@ int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d
     set_error("linear: n=%d must be a multiple of 4 (row stride of out)", n);
     return DDP_E_BADCFG;
   }
-  return launch_linear(d_a, k, d_w, k, d_bias, nullptr, 0, 0, 0, d_out, n, m, n, k, gelu, static_cast<hipStream_t>(stream));
+  return launch_linear(d_a, k, false, d_w, k, d_bias, nullptr, 0, 0, 0, d_out, n, m, n, k, gelu,
+                       static_cast<hipStream_t>(stream));
 }
 
 int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time_in_host, int s, float* d_temb,

@@ -10,59 +10,50 @@ unsigned long long* g_gemm_dbg = nullptr;   // probe: per-block cycle stamps (dd
 
 namespace {
 
-template <int NT, int TAG, class Epi>
-int launch_gemm(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const Epi& epi,
-                hipStream_t st) {
-  if (M <= 0) return DDP_OK;
-  if (K % GEMM_BK != 0 || (lda & 3) || (ldw & 3)) {
-    set_error("gemm: K=%d must be a multiple of %d and lda/ldw multiples of 4", K, GEMM_BK);
+template <int NT, bool A_BLK, int TAG, class Epi>
+int launch_gemm(const GemmArgs& ga_in, const Epi& epi, hipStream_t st) {
+  GemmArgs ga = ga_in;
+  if (ga.M <= 0) return DDP_OK;
+  if (ga.K % GEMM_BK != 0 || (!A_BLK && (ga.lda & 3)) || (ga.ldw & 3)) {
+    set_error("gemm: K=%d must be a multiple of %d and lda/ldw multiples of 4", ga.K, GEMM_BK);
     return DDP_E_BADCFG;
   }
-  const int n_tiles_n = (N + NT * 32 - 1) / (NT * 32);
-  static int variant = -1;        // DDP_GEMM_V=1 selects the LDS-staged-A main loop (A/B experiments)
-  if (variant < 0) {
-    const char* e = getenv("DDP_GEMM_V");
-    variant = e ? atoi(e) : 2;
-  }
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, Epi, TAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(gemm_lds_bytes<NT>()));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok2<NT, Epi, TAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(gemm2_lds_bytes<NT>()));
-    attr_done = true;
+  ga.n_tiles_n = (ga.N + NT * 32 - 1) / (NT * 32);
+  static size_t lds = 0;          // per instantiation
+  if (!lds) {
+    lds = gemm_lds_bytes<NT, Epi>();
+    const char* e = getenv("DDP_GEMM_LDS_KB");            // probe: inflate LDS to force 1 block per CU
+    if (e && size_t(atoi(e)) * 1024 > lds) lds = size_t(atoi(e)) * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, A_BLK, Epi, TAG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   }
   prof_begin(TAG, st);
-  {
-    static int stagger_mul = -1;    // DDP_GEMM_STAGGER = sleeps (of 8128 cycles) per k-tile, x16; default 16 = 1 per k-tile
-    if (stagger_mul < 0) {
-      const char* e = getenv("DDP_GEMM_STAGGER");
-      stagger_mul = e ? atoi(e) : 16;
-    }
-    static int stagger_mode = -1;
-    if (stagger_mode < 0) {
-      const char* e = getenv("DDP_GEMM_STAGGER_MODE");
-      stagger_mode = e ? atoi(e) : 0;
-    }
-    const int stagger = stagger_mul < 0 ? stagger_mul : ((K / GEMM_BK) * stagger_mul / 16) | (stagger_mode << 16);
-    if (variant == 1 || (K % (2 * GEMM_BK)) != 0)
-      hipLaunchKernelGGL((k_gemm_tok<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS),
-                         gemm_lds_bytes<NT>(), st, A, lda, W, ldw, M, N, K, n_tiles_n, epi, stagger, g_gemm_dbg);
-    else
-      hipLaunchKernelGGL((k_gemm_tok2<NT, Epi, TAG>), dim3(gemm_grid(M, n_tiles_n)), dim3(GEMM_THREADS),
-                         gemm2_lds_bytes<NT>(), st, A, lda, W, ldw, M, N, K, n_tiles_n, epi, stagger, g_gemm_dbg);
-  }
+  hipLaunchKernelGGL((k_gemm_tok<NT, A_BLK, Epi, TAG>), dim3(gemm_grid(ga.M, ga.n_tiles_n)), dim3(GEMM_THREADS), lds, st,
+                     ga, epi, g_gemm_dbg);
   prof_end(TAG, st);
   return check_launch("k_gemm_tok");
 }
 
+GemmArgs make_args(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K) {
+  GemmArgs ga;
+  ga.A = A;
+  ga.lda = lda;
+  ga.W = W;
+  ga.ldw = ldw;
+  ga.M = M;
+  ga.N = N;
+  ga.K = K;
+  ga.n_tiles_n = 1;
+  ga.acc_bias = bias;
+  return ga;
+}
+
 }  // namespace
 
-int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
-                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
-                  hipStream_t st, int tag) {
-  EpiBias e;
-  e.bias = bias;
+int launch_linear(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias, const float* add,
+                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu, hipStream_t st,
+                  int tag) {
+  EpiRow e;
   e.add = add;
   e.ld_add = ld_add;
   e.rn = rn;
@@ -75,54 +66,70 @@ int launch_linear(const float* A, int lda, const float* W, int ldw, const float*
     set_error("linear: N=%d, ldo=%d must be a multiple of 4", N, ldo);
     return DDP_E_BADCFG;
   }
-  if (N > 160) {
-    switch (tag) {
-      case TAG_XPROJ: return launch_gemm<8, TAG_XPROJ>(A, lda, W, ldw, M, N, K, e, st);
-      case TAG_FEAT: return launch_gemm<8, TAG_FEAT>(A, lda, W, ldw, M, N, K, e, st);
-      case TAG_VALUE: return launch_gemm<8, TAG_VALUE>(A, lda, W, ldw, M, N, K, e, st);
-      case TAG_FC1: return launch_gemm<8, TAG_FC1>(A, lda, W, ldw, M, N, K, e, st);
-      case TAG_HEAD: return launch_gemm<8, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
-      default: return launch_gemm<8, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
-    }
+  const GemmArgs ga = make_args(A, lda, W, ldw, bias, M, N, K);
+  if (tag == TAG_XPROJ && N > 160 && !a_blk) return launch_gemm<8, false, TAG_XPROJ>(ga, e, st);
+  if (tag == TAG_VALUE && N > 160 && a_blk) return launch_gemm<8, true, TAG_VALUE>(ga, e, st);
+  if (tag == TAG_HEAD && a_blk) {
+    if (N <= 32) return launch_gemm<1, true, TAG_HEAD>(ga, e, st);
+    if (N <= 96) return launch_gemm<3, true, TAG_HEAD>(ga, e, st);
+    if (N <= 160) return launch_gemm<5, true, TAG_HEAD>(ga, e, st);
+    return launch_gemm<8, true, TAG_HEAD>(ga, e, st);
   }
-  if (tag == TAG_HEAD) {
-    if (N <= 32) return launch_gemm<1, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
-    if (N <= 96) return launch_gemm<3, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
-    return launch_gemm<5, TAG_HEAD>(A, lda, W, ldw, M, N, K, e, st);
+  if (a_blk) {
+    set_error("linear: fragment-major input is only instantiated for the value / head call sites");
+    return DDP_E_BADCFG;
   }
-  if (N <= 32) return launch_gemm<1, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
-  if (N <= 96) return launch_gemm<3, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
-  return launch_gemm<5, TAG_GENERIC>(A, lda, W, ldw, M, N, K, e, st);
+  if (N <= 32) return launch_gemm<1, false, TAG_GENERIC>(ga, e, st);
+  if (N <= 96) return launch_gemm<3, false, TAG_GENERIC>(ga, e, st);
+  if (N <= 160) return launch_gemm<5, false, TAG_GENERIC>(ga, e, st);
+  return launch_gemm<8, false, TAG_GENERIC>(ga, e, st);
 }
 
-int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
-                         const float* res, int ldres, const float* gamma, const float* beta,
-                         const float* film, float* out, int ldo, int M, int K, hipStream_t st, int tag) {
-  EpiResLN e;
-  e.bias = bias;
-  e.res = res;
-  e.ldres = ldres;
-  e.gamma = gamma;
-  e.beta = beta;
-  e.film = film;
-  e.out = out;
-  e.ldo = ldo;
-  if (tag == TAG_FC2_LN) return launch_gemm<8, TAG_FC2_LN>(A, lda, W, ldw, M, 256, K, e, st);
-  return launch_gemm<8, TAG_OUTPROJ_LN>(A, lda, W, ldw, M, 256, K, e, st);
+int launch_linear_blk(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias,
+                      const float* add, int ld_add, int rn, int n_tok, float* out_blk, int M, int N, int K, int gelu,
+                      hipStream_t st) {
+  if (N % 256) {
+    set_error("linear_blk: N=%d must be a multiple of 256", N);
+    return DDP_E_BADCFG;
+  }
+  EpiBlk e;
+  e.add = add;
+  e.ld_add = ld_add;
+  e.rn = rn;
+  e.n_tok = n_tok;
+  e.out = out_blk;
+  e.c_out = N;
+  e.gelu = gelu;
+  const GemmArgs ga = make_args(A, lda, W, ldw, bias, M, N, K);
+  if (a_blk) return launch_gemm<8, true, TAG_FC1>(ga, e, st);
+  return launch_gemm<8, false, TAG_FEAT>(ga, e, st);
 }
 
-int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
-                       int n_tok, int w, float* out, int M, hipStream_t st) {
+int launch_linear_res_ln_blk(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias,
+                             const float* res_blk, const float* ga_aff, const float* be_aff, float* out_blk, int M,
+                             int K, hipStream_t st) {
+  EpiResLNBlk e;
+  e.res = res_blk;
+  e.ga = ga_aff;
+  e.be = be_aff;
+  e.out = out_blk;
+  const GemmArgs ga = make_args(A, lda, W, ldw, bias, M, 256, K);
+  if (a_blk) return launch_gemm<8, true, TAG_FC2_LN>(ga, e, st);
+  return launch_gemm<8, false, TAG_OUTPROJ_LN>(ga, e, st);
+}
+
+int launch_linear_samp(const float* A_blk, const float* Wcat, const float* py, const float* px, int n_tok, int w,
+                       float* out, int M, hipStream_t st) {
   EpiSamp e;
   e.py = py;
   e.px = px;
   e.n_tok = n_tok;
   e.w = w;
   e.out = out;
-  return launch_gemm<3, TAG_SAMP>(A, lda, Wcat, 256, M, 96, 256, e, st);
+  const GemmArgs ga = make_args(A_blk, 256, Wcat, 256, nullptr, M, 96, 256);
+  return launch_gemm<3, true, TAG_SAMP>(ga, e, st);
 }
 
 }  // namespace ddp
 
 extern "C" void ddp_debug_set_stamps(void* buf) { ddp::g_gemm_dbg = static_cast<unsigned long long*>(buf); }
-

@@ -19,21 +19,29 @@ void prof_begin(int tag, hipStream_t st);
 void prof_end(int tag, hipStream_t st);
 
 // ---- ddp_gemm.hip -------------------------------------------------------------------------------
-// out = A W^T + bias (+ add[row map]) (+GELU);  A (M,K) lda, W (N,K) ldw; K % 32 == 0, N <= any.
-int launch_linear(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add,
-                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu,
-                  hipStream_t st, int tag = TAG_GENERIC);
-// out = LN(A W^T + bias + res) * gamma + beta [ * (scale+1) + shift ];  N == 256
-int launch_linear_res_ln(const float* A, int lda, const float* W, int ldw, const float* bias,
-                         const float* res, int ldres, const float* gamma, const float* beta,
-                         const float* film, float* out, int ldo, int M, int K, hipStream_t st,
-                         int tag = TAG_OUTPROJ_LN);
-// samp = epilogue(A Wcat^T) with positional tables; Wcat (96,256)
-int launch_linear_samp(const float* A, int lda, const float* Wcat, const float* py, const float* px,
-                       int n_tok, int w, float* out, int M, hipStream_t st);
+// "blk" = fragment-major activation layout (gemm_f32.h); rows padded to 128.
+// row-major out = A W^T + bias (+ add[row map]) (+GELU);  A row-major (lda) or fragment-major (a_blk, K ch)
+int launch_linear(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias, const float* add,
+                  int ld_add, int rn, int n_tok, float* out, int ldo, int M, int N, int K, int gelu, hipStream_t st,
+                  int tag = TAG_GENERIC);
+// fragment-major out (N % 256 == 0) = A W^T + bias (+ row-major add[row map]) (+GELU)
+int launch_linear_blk(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias,
+                      const float* add, int ld_add, int rn, int n_tok, float* out_blk, int M, int N, int K, int gelu,
+                      hipStream_t st);
+// fragment-major out = LN(A W^T + bias + res_blk) * ga + be   (N == 256; ga/be = affine x FiLM)
+int launch_linear_res_ln_blk(const float* A, int lda, bool a_blk, const float* W, int ldw, const float* bias,
+                             const float* res_blk, const float* ga_aff, const float* be_aff, float* out_blk, int M,
+                             int K, hipStream_t st);
+// samp (M,96) row-major = sampling epilogue(A_blk Wcat^T) with positional tables; Wcat (96,256)
+int launch_linear_samp(const float* A_blk, const float* Wcat, const float* py, const float* px, int n_tok, int w,
+                       float* out, int M, hipStream_t st);
 
 // ---- ddp_kernels.hip ----------------------------------------------------------------------------
 int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st);
+// row-major (rows,256) -> fragment-major
+int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st);
+// ga = gamma*(scale+1), be = beta*(scale+1)+shift for S x L (film (S,L,512) = scale|shift); out (S,L,512) = ga|be
+int launch_fold_affine(const float* gamma, const float* beta, const float* film, float* out, int count, hipStream_t st);
 int launch_msda_gather(const float* value, const float* samp, float* out, int rows, int n_tok, int h, int w,
                        hipStream_t st);
 int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);

@@ -46,6 +46,30 @@ __global__ void __launch_bounds__(256) k_nchw_to_tok(const float* __restrict__ i
   }
 }
 
+// fragment-major offset of (row m, channel ch) in a 256-channel buffer (gemm_f32.h)
+__device__ __forceinline__ size_t blk_off256(int m, int ch) {
+  return size_t(m >> 5) * 8192 + (ch >> 5) * 1024 + ((ch & 31) >> 3) * 256 + ((ch & 7) >> 2) * 128 + (m & 31) * 4 + (ch & 3);
+}
+
+// row-major (rows,256) -> fragment-major: one wave per token, lane = 4 channels
+__global__ void __launch_bounds__(256) k_row_to_blk(const float* __restrict__ in, float* __restrict__ out, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(in + size_t(m) * 256 + lane * 4);
+  *reinterpret_cast<f32x4*>(out + blk_off256(m, lane * 4)) = v;
+}
+
+// LayerNorm affine pre-multiplied by FiLM: out[i] = {gamma*(scale+1) | beta*(scale+1)+shift}, i over (S*L)
+__global__ void k_fold_affine(const float* __restrict__ gamma, const float* __restrict__ beta,
+                              const float* __restrict__ film, float* __restrict__ out) {
+  const int c = threadIdx.x;          // 256 channels
+  const float* f = film + size_t(blockIdx.x) * 512;
+  const float sc = f[c] + 1.0f, sh = f[256 + c];
+  out[size_t(blockIdx.x) * 512 + c] = gamma[c] * sc;
+  out[size_t(blockIdx.x) * 512 + 256 + c] = beta[c] * sc + sh;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Deformable attention core (one level): one wave per token; lane = (head = lane>>3, 4 channels).
 // 8 lanes of a head read one 128-B line per bilinear tap; the wave writes its token's 1 KiB row.
@@ -322,7 +346,7 @@ __global__ void __launch_bounds__(256) k_feat_depth(const float* __restrict__ xp
   const f32x4 xp = *reinterpret_cast<const f32x4*>(xproj + (size_t(b) * N + n) * 256 + lane * 4);
   const f32x4 wv = *reinterpret_cast<const f32x4*>(wm + lane * 4);
   const float dv = d[m];
-  *reinterpret_cast<f32x4*>(q + size_t(m) * 256 + lane * 4) = xp + wv * dv;
+  *reinterpret_cast<f32x4*>(q + blk_off256(m, lane * 4)) = xp + wv * dv;   // q is fragment-major
 }
 
 // taps (M,32): column t = dy*3+dx holds w[:,dy,dx] . q[m]; depth[i][j] = relu(sum_t taps[(i+dy-1, j+dx-1)][t] + b) + eps
@@ -397,7 +421,7 @@ __global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ 
         acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
       }
     }
-  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = acc;
+  *reinterpret_cast<f32x4*>(out + blk_off256(m, lane * 4)) = acc;   // fragment-major
 }
 
 // (a) per head token: prob = sigmoid(logit), accumulate;  (b) per map token (h,w): nearest source in the
@@ -452,6 +476,15 @@ static inline int cdiv(long a, long b) { return int((a + b - 1) / b); }
 int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st) {
   hipLaunchKernelGGL(k_nchw_to_tok, dim3(cdiv(N, 64), cdiv(C, 64), R), dim3(256), 0, st, in, out, C, N);
   return check_launch("k_nchw_to_tok");
+}
+int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_row_to_blk, dim3(cdiv(rows, 4)), dim3(256), 0, st, in, out_blk, rows);
+  return check_launch("k_row_to_blk");
+}
+int launch_fold_affine(const float* gamma, const float* beta, const float* film, float* out, int count, hipStream_t st) {
+  if (count <= 0) return DDP_OK;
+  hipLaunchKernelGGL(k_fold_affine, dim3(count), dim3(256), 0, st, gamma, beta, film, out);
+  return check_launch("k_fold_affine");
 }
 int launch_msda_gather(const float* value, const float* samp, float* out, int rows, int n_tok, int h, int w,
                        hipStream_t st) {
