@@ -9,7 +9,7 @@ HBM.  Images shard across ranks with no data-path collective (weak scaling: B im
 only collective is the one-off RCCL broadcast of the frozen weights (outside the timed region).
 
 Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the FFN fc2 GEMM + residual +
-LayerNorm + FiLM epilogue (k_gemm_tok<8,EpiResLN,TAG_FC2_LN>; FFN = 74 % of the loop's flops,
+LayerNorm + FiLM epilogue (k_gemm_tok<8,true,EpiResLNBlk,7>; FFN = 74 % of the loop's flops,
 fp32-MFMA-bound), timed live with HIP events around each of its launches in a second pass of the
 same workload.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
 parity-pinned to golden vectors) timed on this box's host cores on a bounded sample (single
@@ -137,7 +137,7 @@ def main():
         avg_ms = tot.value / max(n.value, 1)
         flops_launch = 2.0 * 256 * 1024 * M            # fc2: (M,1024) x (256,1024)^T, algorithmic
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-        roofline = dict(bound='mfma', kernel='k_gemm_tok<8,EpiResLN,TAG_FC2_LN> (FFN fc2 + residual + LN + FiLM)',
+        roofline = dict(bound='mfma', kernel='k_gemm_tok<8,true,EpiResLNBlk,7> (FFN fc2 + residual + LayerNorm + FiLM)',
                         achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                         launches=n.value, avg_launch_ms=round(avg_ms, 4),
