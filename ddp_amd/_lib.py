@@ -10,10 +10,11 @@ from . import build as _build
 
 MAX_LAYERS = 12
 MAX_STEPS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
+GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
 
@@ -28,6 +29,7 @@ class DdpCfg(C.Structure):
         ('threshold', C.c_float),
         ('bev_in_min', C.c_float * 2), ('bev_in_max', C.c_float * 2),
         ('bev_out_first', C.c_float * 2), ('bev_out_step', C.c_float * 2),
+        ('gemm_mode', C.c_int32),
     ]
 
 

@@ -80,6 +80,11 @@ struct Layout {
   float *wcat[DDP_MAX_LAYERS], *bcat[DDP_MAX_LAYERS], *py[DDP_MAX_LAYERS], *px[DDP_MAX_LAYERS];
   // activations
   float *xproj, *mask, *pred, *feat0, *q, *q1, *v, *s, *samp, *hbuf, *logits, *prob, *snoise, *xtok;
+  // bf16x3 mode: split weights and split fragment-major activations
+  int b3;
+  SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
+      wp_f1[DDP_MAX_LAYERS];
+  unsigned short *q_sb, *q1_sb, *s_sb, *h_sb, *in_sb;   // in_sb: mask / x / feat staging (row-major producers)
   size_t total;
 };
 
@@ -122,6 +127,10 @@ int validate(const ddp_cfg* c) {
   }
   if (c->task == DDP_TASK_BEV && c->num_classes > 32) {
     set_error("bev supports at most 32 classes");
+    return DDP_E_BADCFG;
+  }
+  if (c->gemm_mode != DDP_GEMM_F32_MFMA && c->gemm_mode != DDP_GEMM_BF16X3) {
+    set_error("unknown gemm_mode %d", c->gemm_mode);
     return DDP_E_BADCFG;
   }
   if (c->sampler != DDP_SAMPLER_DDIM && !(c->sampler == DDP_SAMPLER_DDPM && c->task == DDP_TASK_SEG)) {
@@ -178,7 +187,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
   o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
   o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
-  const size_t Mp = (o->M + 127) / 128 * 128;        // fragment-major buffers hold whole 128-token tiles
+  const size_t Mp = (o->M + 255) / 256 * 256;        // fragment-major buffers hold whole block tiles (128 / 256 tokens)
   o->q = cv.take(Mp * 256);                          // fragment-major
   o->q1 = cv.take(Mp * 256);                         // fragment-major
   o->v = cv.take(o->M * 256);                        // row-major (gather taps want a head's 128 B contiguous)
@@ -192,6 +201,44 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->logits = cv.take(o->M * o->ldl);
   o->prob = cv.take(o->M * o->ldl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
+  o->b3 = c->gemm_mode == DDP_GEMM_BF16X3;
+  if (o->b3) {
+    // split weights: 3 bf16 per fp32 = 1.5 floats per element
+    auto takew = [&](size_t rows, size_t K) {
+      SplitW w;
+      w.p = reinterpret_cast<unsigned short*>(cv.take((rows * K * 3 + 1) / 2));
+      w.comp_stride = rows * K;
+      return w;
+    };
+    const int head_rows = c->task == DDP_TASK_DEPTH ? 9 : o->Kc;
+    o->wp_x = takew(256, o->Cx);
+    o->wp_m = takew(256, 256);
+    o->wp_head = takew(head_rows, 256);
+    for (int l = 0; l < DDP_MAX_LAYERS; ++l) {
+      if (l >= o->L) continue;
+      o->wp_v[l] = takew(256, 256);
+      o->wp_cat[l] = takew(96, 256);
+      o->wp_o[l] = takew(256, 256);
+      o->wp_f0[l] = takew(DDP_FFN, 256);
+      o->wp_f1[l] = takew(256, DDP_FFN);
+    }
+    auto takesb = [&](size_t rows, size_t C) {       // SB: 6 bytes per element, rows padded to 256
+      const size_t rp = (rows + 255) / 256 * 256;
+      return reinterpret_cast<unsigned short*>(cv.take((rp * C * 3 + 1) / 2));
+    };
+    o->q_sb = takesb(o->M, 256);
+    o->q1_sb = takesb(o->M, 256);
+    o->s_sb = takesb(o->M, 256);
+    o->h_sb = takesb(o->M, DDP_FFN);
+    size_t in_rows = o->M0 > o->M ? o->M0 : o->M, in_c = 256;
+    if (size_t(o->B) * o->N * o->Cx > in_rows * in_c) {
+      in_rows = size_t(o->B) * o->N;
+      in_c = o->Cx;
+    }
+    o->in_sb = takesb(in_rows, in_c);
+  } else {
+    o->q_sb = o->q1_sb = o->s_sb = o->h_sb = o->in_sb = nullptr;
+  }
   o->total = cv.off * sizeof(float);
 }
 
@@ -287,12 +334,51 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
     DDP_TRY(launch_pack_rows(lw.sampling_offsets_b, 64, lw.attention_weights_b, 32, o.bcat[l], 1, st));
     DDP_TRY(launch_pos_tables(o.wcat[l], o.bcat[l], o.py[l], o.px[l], o.hh, o.wh, st));
   }
+  if (o.b3) {
+    auto wr = [](const SplitW& w) { return const_cast<unsigned short*>(w.p); };
+    DDP_TRY(launch_split_weights(o.wx, o.Cx, 256, o.Cx, wr(o.wp_x), st));
+    if (c->task != DDP_TASK_DEPTH) DDP_TRY(launch_split_weights(o.wm, 256, 256, 256, wr(o.wp_m), st));
+    if (c->task == DDP_TASK_DEPTH) DDP_TRY(launch_split_weights(o.wtap, 256, 9, 256, wr(o.wp_head), st));
+    else DDP_TRY(launch_split_weights(w->head_w, 256, o.Kc, 256, wr(o.wp_head), st));
+    for (int l = 0; l < o.L; ++l) {
+      const ddp_layer_weights& lw = w->layers[l];
+      DDP_TRY(launch_split_weights(lw.value_proj_w, 256, 256, 256, wr(o.wp_v[l]), st));
+      DDP_TRY(launch_split_weights(o.wcat[l], 256, 96, 256, wr(o.wp_cat[l]), st));
+      DDP_TRY(launch_split_weights(lw.output_proj_w, 256, 256, 256, wr(o.wp_o[l]), st));
+      DDP_TRY(launch_split_weights(lw.ffn0_w, 256, DDP_FFN, 256, wr(o.wp_f0[l]), st));
+      DDP_TRY(launch_split_weights(lw.ffn1_w, DDP_FFN, 256, DDP_FFN, wr(o.wp_f1[l]), st));
+    }
+  }
+  return DDP_OK;
+}
+
+// publish a row-major (M,256) activation as the encoder input: fp32 fragment-major q (+ SB copy in bf16x3 mode)
+int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
+  DDP_TRY(launch_row_to_blk(row_major, o.q, int(o.M), st));
+  if (o.b3) DDP_TRY(launch_row_to_sb(row_major, 256, o.q_sb, int(o.M), 256, st));
   return DDP_OK;
 }
 
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
 int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st) {
   const int M = int(o.M);
+  if (o.b3) {
+    // same dataflow on the bf16 matrix cores: q / q1 travel as fp32 fragment-major (residuals) + SB (operands)
+    for (int l = 0; l < o.L; ++l) {
+      const ddp_layer_weights& lw = w->layers[l];
+      DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
+      DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
+      DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
+      DDP_TRY(launch_row_to_sb(o.s, 256, o.s_sb, M, 256, st));
+      DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, o.q, lw.norm0_w, lw.norm0_b, o.q1, o.q1_sb, M, 256,
+                                      st, TAG_OUTPROJ_LN));
+      DDP_TRY(launch_b3_linear_sb(o.q1_sb, o.wp_f0[l], lw.ffn0_b, nullptr, 0, 0, 0, o.h_sb, nullptr, M, DDP_FFN, 256, 1, st,
+                                  TAG_FC1));
+      const float* a = aff + size_t(l) * 512;
+      DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, DDP_FFN, st, TAG_FC2_LN));
+    }
+    return DDP_OK;
+  }
   for (int l = 0; l < o.L; ++l) {
     const ddp_layer_weights& lw = w->layers[l];
     // value / sampling projections (multi_scale_deform_attn.py:313-328)
@@ -413,8 +499,14 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
 
   // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
   DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
-  DDP_TRY(launch_linear(o.xtok, o.Cx, false, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N,
-                        256, o.Cx, 0, st, TAG_XPROJ));
+  if (o.b3) {
+    DDP_TRY(launch_row_to_sb(o.xtok, o.Cx, o.in_sb, o.B * o.N, o.Cx, st));
+    DDP_TRY(launch_b3_linear(o.in_sb, o.wp_x, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256, o.Cx, st,
+                             TAG_XPROJ));
+  } else {
+    DDP_TRY(launch_linear(o.xtok, o.Cx, false, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N,
+                          256, o.Cx, 0, st, TAG_XPROJ));
+  }
   if (cfg->task == DDP_TASK_DEPTH) {
     if (hipMemcpyAsync(o.mask, d_noise, size_t(M0) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("noise copy failed");
@@ -429,12 +521,22 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     const float* aff = o.aff + size_t(s) * o.L * 512;
     // feat = transform(cat[x, mask_t])
     if (cfg->task == DDP_TASK_DEPTH) {
-      DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.q, o.B, o.r, o.N, st));
+      DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.s, o.B, o.r, o.N, st));
+      DDP_TRY(publish_q(o, o.s, st));
     } else {
+      if (o.b3) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
       if (cfg->task == DDP_TASK_BEV) {
-        DDP_TRY(launch_linear(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256,
-                              256, 0, st));
-        DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, geom, st));
+        if (o.b3)
+          DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256, 256, st,
+                                   TAG_XPROJ));
+        else
+          DDP_TRY(launch_linear(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256,
+                                256, 0, st));
+        DDP_TRY(launch_bev_resample(o.feat0, o.s, o.R, geom, st));
+        DDP_TRY(publish_q(o, o.s, st));
+      } else if (o.b3) {
+        DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, o.q, M0, 256, 256, 0, st,
+                                    TAG_FEAT));
       } else {
         DDP_TRY(launch_linear_blk(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q, M0, 256, 256, 0,
                                   st));
@@ -442,8 +544,12 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     }
     DDP_TRY(encoder_forward(weights, o, aff, st));
     if (cfg->task == DDP_TASK_SEG) {
-      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M,
-                            o.Kc, 256, 0, st, TAG_HEAD));
+      if (o.b3)
+        DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256, st,
+                                 TAG_HEAD));
+      else
+        DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M,
+                              o.Kc, 256, 0, st, TAG_HEAD));
       SegUpdateArgs a;
       a.logits = o.logits;
       a.ldl = o.ldl;
@@ -462,7 +568,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       }
       DDP_TRY(launch_seg_update(a, st));
     } else if (cfg->task == DDP_TASK_DEPTH) {
-      DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
+      if (o.b3) DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, st, TAG_HEAD));
+      else DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
       DepthUpdateArgs a;
       a.taps = o.logits;
       a.bias = 0.f;
@@ -479,8 +586,11 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       a.st = sp;
       DDP_TRY(launch_depth_update(a, st));
     } else {
-      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc,
-                            256, 0, st, TAG_HEAD));
+      if (o.b3)
+        DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256, st, TAG_HEAD));
+      else
+        DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc,
+                              256, 0, st, TAG_HEAD));
       BevUpdateArgs a;
       a.logits = o.logits;
       a.num_classes = o.Kc;
@@ -534,18 +644,22 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
   DDP_TRY(fold_affine_dev(weights, o.L, 1, film, o.aff, st));
   if (cfg->task == DDP_TASK_BEV) {
     DDP_TRY(launch_nchw_to_tok(d_feat, o.feat0, o.R, 256, o.N, st));
-    DDP_TRY(launch_bev_resample(o.feat0, o.q, o.R, bev_geom(cfg), st));
+    DDP_TRY(launch_bev_resample(o.feat0, o.s, o.R, bev_geom(cfg), st));
   } else {
     DDP_TRY(launch_nchw_to_tok(d_feat, o.s, o.R, 256, o.N, st));      // row-major staging in `s`
-    DDP_TRY(launch_row_to_blk(o.s, o.q, M, st));
   }
+  DDP_TRY(publish_q(o, o.s, st));
   DDP_TRY(encoder_forward(weights, o, o.aff, st));
   if (cfg->task == DDP_TASK_SEG) {
-    DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
-                          256, 0, st, TAG_HEAD));
+    if (o.b3)
+      DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256, st, TAG_HEAD));
+    else
+      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc,
+                            256, 0, st, TAG_HEAD));
     DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.R, 1, o.Nh, o.Kc, 1.0f, st));
   } else if (cfg->task == DDP_TASK_DEPTH) {
-    DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
+    if (o.b3) DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, st, TAG_HEAD));
+    else DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
     DepthUpdateArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = o.logits;
@@ -561,8 +675,11 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
     a.eps_depth = cfg->min_depth;
     DDP_TRY(launch_depth_update(a, st));
   } else {
-    DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256,
-                          0, st, TAG_HEAD));
+    if (o.b3)
+      DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256, st, TAG_HEAD));
+    else
+      DDP_TRY(launch_linear(o.q, 256, true, weights->head_w, 256, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256,
+                            0, st, TAG_HEAD));
     BevUpdateArgs a;
     memset(&a, 0, sizeof(a));
     a.logits = o.logits;

@@ -36,6 +36,27 @@ int launch_linear_res_ln_blk(const float* A, int lda, bool a_blk, const float* W
 int launch_linear_samp(const float* A_blk, const float* Wcat, const float* py, const float* px, int n_tok, int w,
                        float* out, int M, hipStream_t st);
 
+// ---- ddp_gemm_bf16.hip --------------------------------------------------------------------------
+// bf16x3-split GEMM (gemm_bf16x3.h).  "sb" = split fragment-major bf16 triplets; rows padded to 256.
+struct SplitW {
+  const unsigned short* p;   // [3][rows][K] bf16, K-permuted (k_split_weights)
+  size_t comp_stride;        // elements between components
+};
+int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
+                     int rn, int n_tok, float* out, int ldo, int M, int N, int K, hipStream_t st, int tag);
+int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
+                        int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
+                        hipStream_t st, int tag);
+int launch_b3_linear_res_ln(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* res_blk,
+                            const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
+                            int K, hipStream_t st, int tag);
+int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const float* py, const float* px, int n_tok,
+                          int w, float* out, int M, hipStream_t st);
+// W fp32 (rows, ld) -> Wp[3][rows][K]
+int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);
+// fp32 row-major (rows, C) ld -> SB
+int launch_row_to_sb(const float* in, int ld, unsigned short* out_sb, int rows, int C, hipStream_t st);
+
 // ---- ddp_kernels.hip ----------------------------------------------------------------------------
 int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st);
 // row-major (rows,256) -> fragment-major

@@ -60,6 +60,67 @@ __global__ void __launch_bounds__(256) k_row_to_blk(const float* __restrict__ in
   *reinterpret_cast<f32x4*>(out + blk_off256(m, lane * 4)) = v;
 }
 
+// exact 3-way truncation split of an fp32 into bf16 pieces (see gemm_bf16x3.h)
+__device__ __forceinline__ void split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
+  const unsigned xb = __float_as_uint(x);
+  const unsigned hb = xb & 0xFFFF0000u;
+  const float r = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r) & 0xFFFF0000u;
+  const float r2 = r - __uint_as_float(mb);
+  p1 = (unsigned short)(hb >> 16);
+  p2 = (unsigned short)(mb >> 16);
+  p3 = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// W fp32 (rows, ld) -> Wp[c][row][16b + 8h + u] = piece_c(W[row][16b + 8*(u/4) + 4h + (u%4)])
+__global__ void k_split_weights(const float* __restrict__ W, int ld, int rows, int K, unsigned short* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, 8-slot group)
+  const int groups = K / 8;
+  if (idx >= rows * groups) return;
+  const int row = idx / groups, gq = idx - row * groups;
+  const int b = gq >> 1, h = gq & 1;
+  const size_t comp = size_t(rows) * K;
+  unsigned short* dst = out + size_t(row) * K + 16 * b + 8 * h;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float x = W[size_t(row) * ld + 16 * b + 8 * (u >> 2) + 4 * h + (u & 3)];
+    unsigned short p1, p2, p3;
+    split3(x, p1, p2, p3);
+    dst[u] = p1;
+    dst[comp + u] = p2;
+    dst[2 * comp + u] = p3;
+  }
+}
+
+// fp32 row-major (rows, C) -> SB: one half-wave per token, lane (b, h) handles the 8 channels of its slot
+__global__ void __launch_bounds__(256) k_row_to_sb(const float* __restrict__ in, int ld, unsigned short* __restrict__ out,
+                                                    int rows, int C) {
+  const int slots = C / 8;                                  // (b, h) slots per token
+  const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= long(rows) * slots) return;
+  const int m = int(idx / slots), sl = int(idx - long(m) * slots);
+  const int b = sl >> 1, h = sl & 1;
+  const float* src = in + size_t(m) * ld + 16 * b + 4 * h;
+  const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+  const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
+  unsigned short p[3][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    split3(lo4[u], p[0][u], p[1][u], p[2][u]);
+    split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
+  }
+  char* base = reinterpret_cast<char*>(out) + size_t(m >> 5) * C * 192 + size_t(b) * 3 * 1024 + (h * 32 + (m & 31)) * 16;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint4 v;
+    v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+    v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+    v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+    v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+    *reinterpret_cast<uint4*>(base + c * 1024) = v;
+  }
+}
+
 // LayerNorm affine pre-multiplied by FiLM: out[i] = {gamma*(scale+1) | beta*(scale+1)+shift}, i over (S*L)
 __global__ void k_fold_affine(const float* __restrict__ gamma, const float* __restrict__ beta,
                               const float* __restrict__ film, float* __restrict__ out) {
@@ -346,7 +407,7 @@ __global__ void __launch_bounds__(256) k_feat_depth(const float* __restrict__ xp
   const f32x4 xp = *reinterpret_cast<const f32x4*>(xproj + (size_t(b) * N + n) * 256 + lane * 4);
   const f32x4 wv = *reinterpret_cast<const f32x4*>(wm + lane * 4);
   const float dv = d[m];
-  *reinterpret_cast<f32x4*>(q + blk_off256(m, lane * 4)) = xp + wv * dv;   // q is fragment-major
+  *reinterpret_cast<f32x4*>(q + size_t(m) * 256 + lane * 4) = xp + wv * dv;   // row-major (published by publish_q)
 }
 
 // taps (M,32): column t = dy*3+dx holds w[:,dy,dx] . q[m]; depth[i][j] = relu(sum_t taps[(i+dy-1, j+dx-1)][t] + b) + eps
@@ -421,7 +482,7 @@ __global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ 
         acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
       }
     }
-  *reinterpret_cast<f32x4*>(out + blk_off256(m, lane * 4)) = acc;   // fragment-major
+  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = acc;   // row-major (published by publish_q)
 }
 
 // (a) per head token: prob = sigmoid(logit), accumulate;  (b) per map token (h,w): nearest source in the
@@ -476,6 +537,16 @@ static inline int cdiv(long a, long b) { return int((a + b - 1) / b); }
 int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st) {
   hipLaunchKernelGGL(k_nchw_to_tok, dim3(cdiv(N, 64), cdiv(C, 64), R), dim3(256), 0, st, in, out, C, N);
   return check_launch("k_nchw_to_tok");
+}
+int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st) {
+  const long n = long(rows) * (K / 8);
+  hipLaunchKernelGGL(k_split_weights, dim3(cdiv(n, 256)), dim3(256), 0, st, W, ld, rows, K, out);
+  return check_launch("k_split_weights");
+}
+int launch_row_to_sb(const float* in, int ld, unsigned short* out_sb, int rows, int C, hipStream_t st) {
+  const long n = long(rows) * (C / 8);
+  hipLaunchKernelGGL(k_row_to_sb, dim3(cdiv(n, 256)), dim3(256), 0, st, in, ld, out_sb, rows, C);
+  return check_launch("k_row_to_sb");
 }
 int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st) {
   hipLaunchKernelGGL(k_row_to_blk, dim3(cdiv(rows, 4)), dim3(256), 0, st, in, out_blk, rows);

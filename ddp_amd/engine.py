@@ -12,6 +12,14 @@ from . import schedule
 
 TASKS = {'seg': _lib.TASK_SEG, 'depth': _lib.TASK_DEPTH, 'bev': _lib.TASK_BEV}
 SAMPLERS = {'ddim': _lib.SAMPLER_DDIM, 'ddpm': _lib.SAMPLER_DDPM}
+GEMM_MODES = {'f32': _lib.GEMM_F32_MFMA, 'bf16x3': _lib.GEMM_BF16X3}
+
+
+def default_gemm_mode():
+    """'bf16x3' (fp32-accurate 3-way bf16 split on the bf16 matrix cores) unless DDP_GEMM_MODE=f32 selects the
+    exact f32-input MFMA path."""
+    import os
+    return os.environ.get('DDP_GEMM_MODE', 'bf16x3')
 
 _LAYER_KEYS = {
     'sampling_offsets_w': 'attentions.0.sampling_offsets.weight', 'sampling_offsets_b': 'attentions.0.sampling_offsets.bias',
@@ -102,7 +110,7 @@ class DDPEngine:
                  feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
-                 weights=None):
+                 weights=None, gemm=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -131,6 +139,8 @@ class DDPEngine:
             cfg.head_h, cfg.head_w = out_sizes
         else:
             cfg.head_h, cfg.head_w = (h, w) if head_hw is None else head_hw
+        self.gemm = gemm if gemm is not None else default_gemm_mode()
+        cfg.gemm_mode = GEMM_MODES[self.gemm]
         cfg.accumulation = int(bool(accumulation))
         cfg.bit_scale, cfg.min_depth, cfg.max_depth, cfg.threshold = bit_scale, min_depth, max_depth, threshold
         self.cfg = cfg

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 1
+#define DDP_ABI_VERSION 2
 #define DDP_MAX_LAYERS 12
 #define DDP_MAX_STEPS 64
 #define DDP_EMBED 256
@@ -48,6 +48,12 @@ extern "C" {
 enum { DDP_OK = 0, DDP_E_BADCFG = -1, DDP_E_ALIGN = -2, DDP_E_LAUNCH = -3, DDP_E_NULL = -4 };
 enum { DDP_TASK_SEG = 0, DDP_TASK_DEPTH = 1, DDP_TASK_BEV = 2 };
 enum { DDP_SAMPLER_DDIM = 0, DDP_SAMPLER_DDPM = 1 };
+/* How the channel contractions are evaluated (both are fp32-accurate; csrc/gemm_f32.h, csrc/gemm_bf16x3.h):
+ *   DDP_GEMM_F32_MFMA   exact f32-input MFMA (v_mfma_f32_32x32x2_f32), 157 TFLOP/s ceiling
+ *   DDP_GEMM_BF16X3     every fp32 operand is split exactly into 3 bf16 pieces and the 6 significant cross
+ *                       products run on the bf16 matrix cores with fp32 accumulation (error <= ~3 * 2^-24 per
+ *                       product, i.e. fp32 round-off class), 417 TFLOP/s fp32-equivalent ceiling */
+enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -70,6 +76,7 @@ typedef struct ddp_cfg {
   /* bev grid transform (heads/segm/deformable_head_with_time.py:70-97): per axis (y then x)
    * input [min,max], output first centre and step: c_k = out_first + k * out_step */
   float bev_in_min[2], bev_in_max[2], bev_out_first[2], bev_out_step[2];
+  int32_t gemm_mode;          /* DDP_GEMM_* */
 } ddp_cfg;
 
 typedef struct ddp_layer_weights {            /* decode_head.encoder.layers.<l>.* */
