@@ -372,10 +372,15 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
       DDP_TRY(launch_row_to_sb(o.s, 256, o.s_sb, M, 256, st));
       DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, o.q, lw.norm0_w, lw.norm0_b, o.q1, o.q1_sb, M, 256,
                                       st, TAG_OUTPROJ_LN));
-      DDP_TRY(launch_b3_linear_sb(o.q1_sb, o.wp_f0[l], lw.ffn0_b, nullptr, 0, 0, 0, o.h_sb, nullptr, M, DDP_FFN, 256, 1, st,
-                                  TAG_FC1));
       const float* a = aff + size_t(l) * 512;
-      DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, DDP_FFN, st, TAG_FC2_LN));
+      if (b3_ffn_fused_enabled()) {
+        DDP_TRY(launch_b3_ffn(o.q1_sb, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, st));
+      } else {
+        DDP_TRY(launch_b3_linear_sb(o.q1_sb, o.wp_f0[l], lw.ffn0_b, nullptr, 0, 0, 0, o.h_sb, nullptr, M, DDP_FFN, 256, 1, st,
+                                    TAG_FC1));
+        DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, DDP_FFN, st,
+                                        TAG_FC2_LN));
+      }
     }
     return DDP_OK;
   }

@@ -1,5 +1,8 @@
 // ddp_gemm_bf16.hip - launchers of the bf16x3-split ("fp32-equivalent") token GEMM (gemm_bf16x3.h).
 #include "ddp_internal.h"
+#include <stdlib.h>
+
+#include "ffn_bf16x3.h"
 #include "gemm_bf16x3.h"
 
 namespace ddp {
@@ -112,6 +115,45 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
   e.out = out;
   const b3::Args ga = make_b3(A_sb, wcat, nullptr, M, 96, 256);
   return launch_b3<3, TAG_SAMP>(ga, e, st);
+}
+
+int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
+                  const float* res_blk, const float* ga_aff, const float* be_aff, float* out_f32_blk,
+                  unsigned short* out_sb, int M, hipStream_t st) {
+  if (M <= 0) return DDP_OK;
+  b3::FfnArgs fa;
+  fa.X = X_sb;
+  fa.W1p = w1.p;
+  fa.W2p = w2.p;
+  fa.b1 = b1;
+  fa.b2 = b2;
+  fa.M = M;
+  b3::EpiResLNSB e;
+  e.res = res_blk;
+  e.ga = ga_aff;
+  e.be = be_aff;
+  e.out_f32 = out_f32_blk;
+  e.out_sb = out_sb;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::FFN_LDS_B));
+    attr_done = true;
+  }
+  const int grid = (M + b3::FFN_BM - 1) / b3::FFN_BM;
+  prof_begin(TAG_FC2_LN, st);
+  hipLaunchKernelGGL((b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN>), dim3(grid), dim3(b3::FFN_THREADS), b3::FFN_LDS_B, st, fa, e);
+  prof_end(TAG_FC2_LN, st);
+  return check_launch("b3::k_ffn");
+}
+
+bool b3_ffn_fused_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DDP_FFN_FUSED");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
 }
 
 }  // namespace ddp
