@@ -129,7 +129,8 @@ int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2
   fa.b2 = b2;
   fa.M = M;
   b3::EpiResLNSB e;
-  e.res = res_blk;
+  (void)res_blk;       // the residual is the kernel's own input: rebuilt from the resident fragments
+  e.res = nullptr;
   e.ga = ga_aff;
   e.be = be_aff;
   e.out_f32 = out_f32_blk;

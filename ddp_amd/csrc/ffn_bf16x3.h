@@ -27,7 +27,9 @@ namespace b3 {
 constexpr int FFN_BM = 128;
 constexpr int FFN_THREADS = 256;
 constexpr int FFN_STAGE_B = 48 * 1024;
-constexpr size_t FFN_LDS_B = 2 * FFN_STAGE_B;
+constexpr int FFN_RING = 3;                                   // stages in flight: compute q, landed q+1, landing q+2
+constexpr int FFN_B1_OFF = FFN_RING * FFN_STAGE_B;            // fc1 bias (4 KB) behind the ring
+constexpr size_t FFN_LDS_B = size_t(FFN_B1_OFF) + 4096;
 
 struct FfnArgs {
   const unsigned short* X;     // SB input (256 ch)
@@ -37,6 +39,14 @@ struct FfnArgs {
   const float* b2;             // (256)
   int M;
 };
+
+__device__ __forceinline__ void wait_vm12() { __builtin_amdgcn_s_waitcnt(0x0F7C); }   // vmcnt(12): one DMA stage may stay in flight
+
+// element u (0..7) of a packed bf16x8 fragment as fp32
+__device__ __forceinline__ float bf_elem(const u32x4& v, int u) {
+  const unsigned w = v[u >> 1];
+  return __uint_as_float((u & 1) ? (w & 0xFFFF0000u) : (w << 16));
+}
 
 template <class Epi, int TAG>
 __global__ void __launch_bounds__(FFN_THREADS, 1)
@@ -66,37 +76,42 @@ k_ffn(FfnArgs fa, Epi epi) {
   }
   // W2 stage s2 (0/1) of chunk hc: rows [0,256) x hidden [hc*64 + s2*32, +32): piece = 16 rows x 64 B
   const unsigned w2_lane = unsigned((lane >> 2) * 1024 * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
-  auto dma_w1 = [&](int hc, int s1, int stage) {
+  auto dma_w1 = [&](int hc, int s1, int slot, int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
+      if (i < i0 || i >= i1) continue;
       const int p = wave * 12 + i;
       const int comp = p >> 4, rb = p & 15;
       const char* src = reinterpret_cast<const char*>(fa.W1p) + (size_t(comp) * W1_COMP + size_t(hc * 64 + rb * 4) * 256) * 2 + s1 * 256;
-      lds_dma16(reinterpret_cast<const float*>(src), w1_lane[i & 3], lds0 + unsigned(stage * FFN_STAGE_B + comp * 16384 + rb * 1024));
+      lds_dma16(reinterpret_cast<const float*>(src), w1_lane[i & 3], lds0 + unsigned(slot * FFN_STAGE_B + comp * 16384 + rb * 1024));
     }
   };
-  auto dma_w2 = [&](int hc, int s2, int stage) {
+  auto dma_w2 = [&](int hc, int s2, int slot, int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
+      if (i < i0 || i >= i1) continue;
       const int p = wave * 12 + i;
       const int comp = p >> 4, rb = p & 15;
       const char* src = reinterpret_cast<const char*>(fa.W2p) + (size_t(comp) * W2_COMP + size_t(rb * 16) * 1024) * 2 + (hc * 2 + s2) * 64;
-      lds_dma16(reinterpret_cast<const float*>(src), w2_lane, lds0 + unsigned(stage * FFN_STAGE_B + comp * 16384 + rb * 1024));
+      lds_dma16(reinterpret_cast<const float*>(src), w2_lane, lds0 + unsigned(slot * FFN_STAGE_B + comp * 16384 + rb * 1024));
     }
   };
-  // fragment reads
+  // fragment reads (per-lane base + slot base + compile-time offsets)
   const char* lbase = reinterpret_cast<const char*>(smem);
-  auto frag1 = [&](int stage, int comp, int t, int b) -> u32x4 {      // W1 stage: row t*32+j, K16 step b (0..7)
-    const int row = t * 32 + j;
-    return *reinterpret_cast<const u32x4*>(lbase + stage * FFN_STAGE_B + comp * 16384 + row * 256 + (((2 * b + h) ^ (j & 15)) << 4));
+  const int f1_lane = j * 256;                        // W1 stage: row t*32+j, 16 slots of 16 B, swizzle (j & 15)
+  const int f2_lane = j * 64;                         // W2 stage: row t*32+j, 4 slots, swizzle ((j>>2)&3)
+  auto frag1 = [&](int slot, int comp, int t, int b) -> u32x4 {      // K16 step b (0..7)
+    return *reinterpret_cast<const u32x4*>(lbase + slot * FFN_STAGE_B + comp * 16384 + t * 8192 + f1_lane + (((2 * b + h) ^ (j & 15)) << 4));
   };
-  auto frag2 = [&](int stage, int comp, int t, int ks) -> u32x4 {     // W2 stage: row t*32+j, K16 step ks (0..1)
-    const int row = t * 32 + j;
-    return *reinterpret_cast<const u32x4*>(lbase + stage * FFN_STAGE_B + comp * 16384 + row * 64 + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
+  auto frag2 = [&](int slot, int comp, int t, int ks) -> u32x4 {     // K16 step ks (0..1)
+    return *reinterpret_cast<const u32x4*>(lbase + slot * FFN_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
   };
+  auto nxt = [](int s) { return s == FFN_RING - 1 ? 0 : s + 1; };
 
-  // ---- prologue: first weight stage + this wave's input fragments (kept in registers for the whole kernel)
-  dma_w1(0, 0, 0);
+  // ---- prologue: two weight stages, fc1 bias -> LDS, this wave's input fragments (registers, whole kernel)
+  dma_w1(0, 0, 0, 0, 12);
+  dma_w1(0, 1, 1, 0, 12);
+  *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + FFN_B1_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(fa.b1 + tid * 4);
   u32x4 xa[16][3];
   {
     const char* xs = reinterpret_cast<const char*>(fa.X) + (size_t(m0 >> 5) + wave) * 256 * 192 + lane * 16;
@@ -121,70 +136,131 @@ k_ffn(FfnArgs fa, Epi epi) {
     for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(xa[b][c]));
   __syncthreads();
 
-  // stage sequence per chunk: W1(s1=0) W1(s1=1) W2(s2=0) W2(s2=1); ring slot alternates 0,1,0,1
+  // Stage sequence per chunk: W1(k 0..127) W1(k 128..255) W2(hidden 0..31) W2(hidden 32..63); stage q lives in
+  // ring slot q % 3 and its DMA is issued at the start of stage q-2.
+  int slot = 0;
+  const float* b1s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + FFN_B1_OFF);
   for (int hc = 0; hc < 16; ++hc) {
     f32x16 acc1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(fa.b1 + hc * 64 + t * 32 + 8 * g + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + hc * 64 + t * 32 + 8 * g + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc1[t][4 * g + e] = b[e];
       }
+    // Scheduling rules for one wave per SIMD (MI355X_MICROARCH.md, latency table):
+    //  * a dependent MFMA right behind its producer is free only when NOTHING is issued between them, and the
+    //    loads / GELU / DMA must sit somewhere -> two accumulator chains (a tile pair) are always interleaved;
+    //  * a fragment is re-read into its own registers as soon as its last MFMA of the block has issued (w2 after
+    //    2 MFMAs, w1 after 6, w0 after 12 - terms ordered for that), >= 6 MFMAs (192 cycles) before its next use;
+    //  * the next-next stage's 12 DMA pieces are spread over the 8 blocks of a stage.
+#define DDP_FFN_BLOCK(A0, A1, X0, X1, X2, RELOAD2, RELOAD1, RELOAD0, FILL1, FILL0)                                   \
+  A0 = mma(w[0][2], X0, A0);                                                                                        \
+  A1 = mma(w[1][2], X0, A1);                                                                                        \
+  RELOAD2;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  A0 = mma(w[0][1], X1, A0);                                                                                        \
+  A1 = mma(w[1][1], X1, A1);                                                                                        \
+  A0 = mma(w[0][1], X0, A0);                                                                                        \
+  A1 = mma(w[1][1], X0, A1);                                                                                        \
+  FILL1;                                                                                                            \
+  RELOAD1;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  A0 = mma(w[0][0], X2, A0);                                                                                        \
+  A1 = mma(w[1][0], X2, A1);                                                                                        \
+  A0 = mma(w[0][0], X1, A0);                                                                                        \
+  A1 = mma(w[1][0], X1, A1);                                                                                        \
+  A0 = mma(w[0][0], X0, A0);                                                                                        \
+  A1 = mma(w[1][0], X0, A1);                                                                                        \
+  FILL0;                                                                                                            \
+  RELOAD0;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+
     // ---- phase 1: acc1 += W1[chunk] . x over K = 256 (two 128-k stages)
 #pragma unroll
     for (int s1 = 0; s1 < 2; ++s1) {
-      if (s1 == 0) dma_w1(hc, 1, 1); else dma_w2(hc, 0, 0);          // prefetch the next stage into the other slot
+      const int dslot = nxt(nxt(slot));
+      u32x4 w[2][3];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const u32x4 w0 = frag1(s1, 0, t, b), w1 = frag1(s1, 1, t, b), w2 = frag1(s1, 2, t, b);
-          const int kb = s1 * 8 + b;
-          acc1[t] = mma(w2, xa[kb][0], acc1[t]);
-          acc1[t] = mma(w0, xa[kb][2], acc1[t]);
-          acc1[t] = mma(w1, xa[kb][1], acc1[t]);
-          acc1[t] = mma(w1, xa[kb][0], acc1[t]);
-          acc1[t] = mma(w0, xa[kb][1], acc1[t]);
-          acc1[t] = mma(w0, xa[kb][0], acc1[t]);
-        }
-      wait_vm0();
-      __syncthreads();
-    }
-    // ---- GELU + exact split: the result is the B operand of phase 2 (k-block = (tile, quad pair))
-    u32x4 hp[4][3];
+        for (int c = 0; c < 3; ++c) w[t][c] = frag1(slot, c, t, 0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = gelu_fast(acc1[t][8 * gp + e]);
-        split8(x, hp[t * 2 + gp][0], hp[t * 2 + gp][1], hp[t * 2 + gp][2]);
+      for (int b = 0; b < 8; ++b) {
+        const int kb = s1 * 8 + b;
+        const bool nb = b + 1 < 8;
+        DDP_FFN_BLOCK(acc1[0], acc1[1], xa[kb][0], xa[kb][1], xa[kb][2],
+                      if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
+                      if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
+                      if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); },
+                      dma_w2(hc, s1, dslot, b, b + 1),
+                      if (b < 4) dma_w2(hc, s1, dslot, 8 + b, 9 + b))
       }
+      wait_vm12();
+      __syncthreads();
+      slot = nxt(slot);
+    }
+    // ---- GELU + exact split: the result IS the B operand of phase 2 (k-block kb = (tile kb/2, quad pair kb%2));
+    //      block 0 here, block kb+1 under block kb's MFMAs
+    u32x4 hcur[3];
+    float xg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xg[e] = gelu_fast(acc1[0][e]);
+    split8(xg, hcur[0], hcur[1], hcur[2]);
     // ---- phase 2: acc2 += W2[:, chunk] . h (two 32-hidden stages, each = one tile of the chunk)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      if (s2 == 0) dma_w2(hc, 1, 1);
-      else if (hc + 1 < 16) dma_w1(hc + 1, 0, 0);
+      const bool more = hc + 1 < 16;
+      const int dslot = nxt(nxt(slot));
+      u32x4 w[2][3];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const u32x4 w0 = frag2(s2, 0, t, ks), w1 = frag2(s2, 1, t, ks), w2 = frag2(s2, 2, t, ks);
-          const int kb = s2 * 2 + ks;
-          acc2[t] = mma(w2, hp[kb][0], acc2[t]);
-          acc2[t] = mma(w0, hp[kb][2], acc2[t]);
-          acc2[t] = mma(w1, hp[kb][1], acc2[t]);
-          acc2[t] = mma(w1, hp[kb][0], acc2[t]);
-          acc2[t] = mma(w0, hp[kb][1], acc2[t]);
-          acc2[t] = mma(w0, hp[kb][0], acc2[t]);
+        for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kb = s2 * 2 + ks;
+        const int kn = kb + 1;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+          const int blk = ks * 4 + tp;
+          const bool nb = blk + 1 < 8;
+          const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+          DDP_FFN_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2],
+                        if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
+                        if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
+                        if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
+                        {
+                          if (more) dma_w1(hc + 1, s2, dslot, blk, blk + 1);
+                          if (kb < 3) xg[2 * tp] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
+                        },
+                        {
+                          if (more && blk < 4) dma_w1(hc + 1, s2, dslot, 8 + blk, 9 + blk);
+                          if (kb < 3) xg[2 * tp + 1] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
+                        })
         }
-      wait_vm0();
+        if (kb < 3) split8(xg, hcur[0], hcur[1], hcur[2]);
+      }
+      if (more) wait_vm12(); else wait_vm0();
       __syncthreads();
+      slot = nxt(slot);
     }
   }
+#undef DDP_FFN_BLOCK
+
+  // residual: x itself, rebuilt exactly from the resident fragments (same lane <-> (token, channel) map as acc2)
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = 2 * t + (g >> 1), u = 4 * (g & 1) + e;
+        const float x = (bf_elem(xa[b][0], u) + bf_elem(xa[b][1], u)) + bf_elem(xa[b][2], u);
+        acc2[t][4 * g + e] += x;
+      }
 
   LaneCtx cx;
   cx.m = m0 + wave * 32 + j;

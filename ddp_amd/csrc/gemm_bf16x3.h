@@ -321,7 +321,7 @@ struct EpiSB {
   }
 };
 
-// y = acc + res (fp32 fragment-major); LayerNorm; affine x FiLM; out as fp32 fragment-major + SB
+// y = acc + res (fp32 fragment-major; nullptr = the caller already added it); LayerNorm; affine x FiLM; out as fp32 fragment-major + SB
 struct EpiResLNSB {
   static constexpr bool kNeedsPatch = false;
   const float* res;
@@ -340,10 +340,11 @@ struct EpiResLNSB {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 r = *reinterpret_cast<const f32x4*>(rsrc + t * 1024 + g * 256);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (res) r = *reinterpret_cast<const f32x4*>(rsrc + t * 1024 + g * 256);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = acc[t][4 * g + e] + r[e];
+          const float v = res ? acc[t][4 * g + e] + r[e] : acc[t][4 * g + e];
           acc[t][4 * g + e] = v;
           s += v;
         }
