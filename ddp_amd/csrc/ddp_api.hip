@@ -352,34 +352,34 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
   return DDP_OK;
 }
 
-// publish a row-major (M,256) activation as the encoder input: fp32 fragment-major q (+ SB copy in bf16x3 mode)
+// publish a row-major (M,256) activation as the encoder input: fp32 fragment-major q, or SB in bf16x3 mode
 int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
-  DDP_TRY(launch_row_to_blk(row_major, o.q, int(o.M), st));
-  if (o.b3) DDP_TRY(launch_row_to_sb(row_major, 256, o.q_sb, int(o.M), 256, st));
-  return DDP_OK;
+  if (o.b3) return launch_row_to_sb(row_major, 256, o.q_sb, int(o.M), 256, st);
+  return launch_row_to_blk(row_major, o.q, int(o.M), st);
 }
 
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
 int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st) {
   const int M = int(o.M);
   if (o.b3) {
-    // same dataflow on the bf16 matrix cores: q / q1 travel as fp32 fragment-major (residuals) + SB (operands)
+    // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
+    // of an element sum to its fp32 value exactly)
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
       DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
       DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
       DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
       DDP_TRY(launch_row_to_sb(o.s, 256, o.s_sb, M, 256, st));
-      DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, o.q, lw.norm0_w, lw.norm0_b, o.q1, o.q1_sb, M, 256,
-                                      st, TAG_OUTPROJ_LN));
+      DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
+                                      o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));
       const float* a = aff + size_t(l) * 512;
       if (b3_ffn_fused_enabled()) {
-        DDP_TRY(launch_b3_ffn(o.q1_sb, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, st));
+        DDP_TRY(launch_b3_ffn(o.q1_sb, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, a, a + 256, nullptr, o.q_sb, M, st));
       } else {
         DDP_TRY(launch_b3_linear_sb(o.q1_sb, o.wp_f0[l], lw.ffn0_b, nullptr, 0, 0, 0, o.h_sb, nullptr, M, DDP_FFN, 256, 1, st,
                                     TAG_FC1));
-        DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, o.q1, a, a + 256, o.q, o.q_sb, M, DDP_FFN, st,
-                                        TAG_FC2_LN));
+        DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, nullptr, o.q1_sb, a, a + 256, nullptr, o.q_sb, M,
+                                        DDP_FFN, st, TAG_FC2_LN));
       }
     }
     return DDP_OK;
@@ -540,7 +540,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         DDP_TRY(launch_bev_resample(o.feat0, o.s, o.R, geom, st));
         DDP_TRY(publish_q(o, o.s, st));
       } else if (o.b3) {
-        DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, o.q, M0, 256, 256, 0, st,
+        DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, nullptr, M0, 256, 256, 0, st,
                                     TAG_FEAT));
       } else {
         DDP_TRY(launch_linear_blk(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q, M0, 256, 256, 0,

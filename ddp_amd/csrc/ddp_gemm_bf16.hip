@@ -92,10 +92,11 @@ int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float
 }
 
 int launch_b3_linear_res_ln(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* res_blk,
-                            const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
-                            int K, hipStream_t st, int tag) {
+                            const unsigned short* res_sb, const float* ga_aff, const float* be_aff, float* out_f32_blk,
+                            unsigned short* out_sb, int M, int K, hipStream_t st, int tag) {
   b3::EpiResLNSB e;
   e.res = res_blk;
+  e.res_sb = res_sb;
   e.ga = ga_aff;
   e.be = be_aff;
   e.out_f32 = out_f32_blk;
@@ -118,8 +119,8 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
 }
 
 int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* res_blk, const float* ga_aff, const float* be_aff, float* out_f32_blk,
-                  unsigned short* out_sb, int M, hipStream_t st) {
+                  const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
+                  hipStream_t st) {
   if (M <= 0) return DDP_OK;
   b3::FfnArgs fa;
   fa.X = X_sb;
@@ -129,8 +130,8 @@ int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2
   fa.b2 = b2;
   fa.M = M;
   b3::EpiResLNSB e;
-  (void)res_blk;       // the residual is the kernel's own input: rebuilt from the resident fragments
-  e.res = nullptr;
+  e.res = nullptr;      // the residual is the kernel's own input: rebuilt from the resident fragments
+  e.res_sb = nullptr;
   e.ga = ga_aff;
   e.be = be_aff;
   e.out_f32 = out_f32_blk;

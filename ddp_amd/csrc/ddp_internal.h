@@ -48,14 +48,14 @@ int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
                         hipStream_t st, int tag);
 int launch_b3_linear_res_ln(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* res_blk,
-                            const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
-                            int K, hipStream_t st, int tag);
+                            const unsigned short* res_sb, const float* ga_aff, const float* be_aff, float* out_f32_blk,
+                            unsigned short* out_sb, int M, int K, hipStream_t st, int tag);
 int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const float* py, const float* px, int n_tok,
                           int w, float* out, int M, hipStream_t st);
 // whole FFN block (fc1 + GELU + fc2 + residual + LayerNorm + FiLM) in one kernel (ffn_bf16x3.h)
 int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* res_blk, const float* ga_aff, const float* be_aff, float* out_f32_blk,
-                  unsigned short* out_sb, int M, hipStream_t st);
+                  const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
+                  hipStream_t st);
 bool b3_ffn_fused_enabled();
 // W fp32 (rows, ld) -> Wp[3][rows][K]
 int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);

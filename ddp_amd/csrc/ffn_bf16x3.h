@@ -212,7 +212,7 @@ k_ffn(FfnArgs fa, Epi epi) {
     // ---- phase 2: acc2 += W2[:, chunk] . h (two 32-hidden stages, each = one tile of the chunk)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const bool more = hc + 1 < 16;
+      const int hn = hc + 1 < 16 ? hc + 1 : 15;      // last chunk: a harmless re-fetch keeps the loop branch-free
       const int dslot = nxt(nxt(slot));
       u32x4 w[2][3];
 #pragma unroll
@@ -233,22 +233,23 @@ k_ffn(FfnArgs fa, Epi epi) {
                         if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
                         if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
                         {
-                          if (more) dma_w1(hc + 1, s2, dslot, blk, blk + 1);
+                          dma_w1(hn, s2, dslot, blk, blk + 1);
                           if (kb < 3) xg[2 * tp] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
                         },
                         {
-                          if (more && blk < 4) dma_w1(hc + 1, s2, dslot, 8 + blk, 9 + blk);
+                          if (blk < 4) dma_w1(hn, s2, dslot, 8 + blk, 9 + blk);
                           if (kb < 3) xg[2 * tp + 1] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
                         })
         }
         if (kb < 3) split8(xg, hcur[0], hcur[1], hcur[2]);
       }
-      if (more) wait_vm12(); else wait_vm0();
+      wait_vm12();
       __syncthreads();
       slot = nxt(slot);
     }
   }
 #undef DDP_FFN_BLOCK
+  wait_vm0();
 
   // residual: x itself, rebuilt exactly from the resident fragments (same lane <-> (token, channel) map as acc2)
 #pragma unroll

@@ -321,10 +321,13 @@ struct EpiSB {
   }
 };
 
-// y = acc + res (fp32 fragment-major; nullptr = the caller already added it); LayerNorm; affine x FiLM; out as fp32 fragment-major + SB
+// y = acc + res; LayerNorm; affine x FiLM; out as SB (+ optional fp32 fragment-major copy).
+// The residual comes as SB (res_sb: the three bf16 pieces sum to the fp32 value exactly), as fp32 fragment-major
+// (res), or not at all (both null: the caller added it).
 struct EpiResLNSB {
   static constexpr bool kNeedsPatch = false;
   const float* res;
+  const unsigned short* res_sb;
   const float* ga;
   const float* be;
   float* out_f32;
@@ -334,21 +337,41 @@ struct EpiResLNSB {
   __device__ __forceinline__ void run(f32x16 (&acc)[NT], const LaneCtx& cx) const {
     static_assert(NT == 8, "LayerNorm epilogue needs the full 256-channel row");
     const size_t goff = size_t(cx.m_base >> 5) * 32 * 256 + cx.lane * 4;
-    const float* rsrc = res + goff;
     float s = 0.f;
+    if (res_sb) {
+      const char* rs = reinterpret_cast<const char*>(res_sb) + size_t(cx.m_base >> 5) * 256 * 192 + cx.lane * 16;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const char* p = rs + size_t(2 * t + gp) * 3 * 1024;
+          const u32x4 p1 = *reinterpret_cast<const u32x4*>(p);
+          const u32x4 p2 = *reinterpret_cast<const u32x4*>(p + 1024);
+          const u32x4 p3 = *reinterpret_cast<const u32x4*>(p + 2048);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const unsigned w1 = p1[u >> 1], w2 = p2[u >> 1], w3 = p3[u >> 1];
+            const float r = (__uint_as_float((u & 1) ? (w1 & 0xFFFF0000u) : (w1 << 16)) +
+                             __uint_as_float((u & 1) ? (w2 & 0xFFFF0000u) : (w2 << 16))) +
+                            __uint_as_float((u & 1) ? (w3 & 0xFFFF0000u) : (w3 << 16));
+            acc[t][8 * gp + u] += r;
+          }
+        }
+    } else if (res) {
+      const float* rsrc = res + goff;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(rsrc + t * 1024 + g * 256);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][4 * g + e] += r[e];
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (res) r = *reinterpret_cast<const f32x4*>(rsrc + t * 1024 + g * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = res ? acc[t][4 * g + e] + r[e] : acc[t][4 * g + e];
-          acc[t][4 * g + e] = v;
-          s += v;
-        }
-      }
+      for (int r = 0; r < 16; ++r) s += acc[t][r];
     const float mean = half_sum(s) * (1.0f / 256.0f);
     float q = 0.f;
 #pragma unroll
@@ -360,7 +383,7 @@ struct EpiResLNSB {
         q += d * d;
       }
     const float rstd = 1.0f / sqrtf(half_sum(q) * (1.0f / 256.0f) + 1e-5f);
-    float* dst = out_f32 + goff;
+    float* dst = out_f32 ? out_f32 + goff : nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -374,7 +397,7 @@ struct EpiResLNSB {
           v[e] = acc[t][4 * g + e] * (rstd * a[e]) + b[e];
           acc[t][4 * g + e] = v[e];
         }
-        *reinterpret_cast<f32x4*>(dst + t * 1024 + g * 256) = v;
+        if (dst) *reinterpret_cast<f32x4*>(dst + t * 1024 + g * 256) = v;
       }
       store_tile_sb(acc[t], out_sb, 256, cx.m_base, t, cx.lane);
     }
