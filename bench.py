@@ -8,10 +8,12 @@ torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path 
 HBM.  Images shard across ranks with no data-path collective (weak scaling: B images per GPU); the
 only collective is the one-off RCCL broadcast of the frozen weights (outside the timed region).
 
-Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the FFN fc2 GEMM + residual +
-LayerNorm + FiLM epilogue (k_gemm_tok<8,true,EpiResLNBlk,7>; FFN = 74 % of the loop's flops,
-fp32-MFMA-bound), timed live with HIP events around each of its launches in a second pass of the
-same workload.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
+Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the fused FFN block of a decoder
+layer (b3::k_ffn: fc1 + GELU + fc2 + residual + LayerNorm + FiLM, 74 % of the loop's flops; in the
+default bf16x3 engine every fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the
+bound is the dense bf16 MFMA peak / 6), timed live with HIP events around each of its launches in a
+second pass of the same workload.  With DDP_GEMM_MODE=f32 the dominant kernel is the fp32-MFMA fc2
+GEMM + LayerNorm epilogue and the bound is the fp32 MFMA peak.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
 parity-pinned to golden vectors) timed on this box's host cores on a bounded sample (single
 512x1024 images of the same workload), rank 0 at N=1 only.
 """
@@ -39,6 +41,8 @@ WORKLOADS = {
                                     bit_scale=0.01, accumulation=True, num_layers=6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles/SIMD)
+B3_PRODUCTS = 6                    # bf16 MFMA products per fp32-equivalent product in the bf16x3 engine
 TAG_FC2_LN = 7
 
 
@@ -135,17 +139,30 @@ def main():
         _lib.check(lib.ddp_profile_end(C.byref(tot), C.byref(n)))
         torch.cuda.synchronize()
         avg_ms = tot.value / max(n.value, 1)
-        flops_launch = 2.0 * 256 * 1024 * M            # fc2: (M,1024) x (256,1024)^T, algorithmic
+        if eng.gemm == 'bf16x3' and os.environ.get('DDP_FFN_FUSED', '1') != '0':
+            # fused FFN: fc1 (M,256)x(1024,256)^T + fc2 (M,1024)x(256,1024)^T, algorithmic fp32 flops
+            flops_launch = 2.0 * 2 * 256 * 1024 * M
+            peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
+            kernel = ('b3::k_ffn<EpiResLNSB,7> (FFN fc1 + GELU + fc2 + residual + LayerNorm + FiLM; fp32 products as '
+                      '6 bf16 MFMA products, peak = 2500 TFLOP/s dense bf16 / 6)')
+        elif eng.gemm == 'bf16x3':
+            flops_launch = 2.0 * 256 * 1024 * M
+            peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
+            kernel = 'b3::k_gemm<8,EpiResLNSB,7> (FFN fc2 + residual + LayerNorm + FiLM; peak = 2500 TFLOP/s bf16 / 6)'
+        else:
+            flops_launch = 2.0 * 256 * 1024 * M            # fc2: (M,1024) x (256,1024)^T, algorithmic
+            peak = FP32_MFMA_PEAK_TFLOPS
+            kernel = 'k_gemm_tok<8,true,EpiResLNBlk,7> (FFN fc2 + residual + LayerNorm + FiLM; fp32 MFMA)'
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-        roofline = dict(bound='mfma', kernel='k_gemm_tok<8,true,EpiResLNBlk,7> (FFN fc2 + residual + LayerNorm + FiLM)',
-                        achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+        roofline = dict(bound='mfma', kernel=kernel,
+                        achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
+                        frac=round(achieved / peak, 4), traffic=None,
                         launches=n.value, avg_launch_ms=round(avg_ms, 4),
                         flops_per_launch=flops_launch)
         # whole-loop dense-contraction rate for context
         loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes']) * float(M) * K
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
-        roofline['loop_frac'] = round(roofline['loop_tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)
+        roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
 
     # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
     cpu = None
@@ -178,11 +195,13 @@ def main():
             'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node',
             'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (bf16x3-split MFMA products, fp32 accumulate)' if eng.gemm == 'bf16x3' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': args.workload + ' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
                                                    'per GPU; x (8,256,128,256), random-init weights)',
                        'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
-                       'parallelism': f'dp{world} (independent images, weights broadcast once)'},
+                       'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'images_per_s_per_gpu': round(images_per_s / world, 3),
             'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
         }

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Summarise one scripts/gpu_round.sh visit (gpurun_out/<tag>/) into profiles/<tag>_*: the rocprofv3 kernel-stats
+table, the bench line, the GPU test tail, and a per-kernel PMC summary (average per launch):
+HBM bytes = FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 128-B requests of wide
+coalesced streaming reads at 64 B, so it is doubled as MI355X_MICROARCH.md "HBM" prescribes; WRITE_SIZE is
+reported raw = uncalibrated), MFMA-busy and wave-cycle counters (summed over the chip)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+print_only = '--print-only' in sys.argv
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', tag)
+dst = os.path.join(root, 'profiles')
+
+
+def short(name):
+    for a in ('void ', 'ddp::(anonymous namespace)::', 'ddp::'):
+        name = name.replace(a, '')
+    return name.split('(')[0][:70]
+
+
+def pmc(dirname):
+    files = glob.glob(os.path.join(src, dirname, '**', '*counter_collection.csv'), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
+
+
+summary = {}
+hbm = pmc('pmc_hbm_rd')
+for k, d in pmc('pmc_hbm_wr').items():
+    hbm.setdefault(k, {}).update(d)
+for k, d in hbm.items():
+    e = summary.setdefault(k, {})
+    if 'FETCH_SIZE' in d:
+        e['launches_profiled'] = d['FETCH_SIZE'][1]
+        e['hbm_read_bytes_per_launch'] = round(d['FETCH_SIZE'][0] * 1024 * 2)      # x2: gfx950 correction
+        e['fetch_size_raw_kb'] = round(d['FETCH_SIZE'][0], 1)
+    if 'WRITE_SIZE' in d:
+        e['hbm_write_bytes_per_launch_uncalibrated'] = round(d['WRITE_SIZE'][0] * 1024)
+for k, d in pmc('pmc_mfma').items():
+    e = summary.setdefault(k, {})
+    for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY'):
+        if c in d:
+            e[c] = round(d[c][0])
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in e and e.get('GRBM_GUI_ACTIVE'):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy over 1024 SIMDs
+        e['mfma_busy_frac'] = round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (e['GRBM_GUI_ACTIVE'] / 8.0), 4)
+rows = sorted(summary.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0) * kv[1].get('launches_profiled', 1))
+for k, e in rows[:14]:
+    print(k, json.dumps(e))
+if print_only:
+    sys.exit(0)
+os.makedirs(dst, exist_ok=True)
+json.dump(dict(rows), open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
+for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'), ('bench.json', f'{tag}_bench.json'),
+                  ('pytest_gpu.txt', f'{tag}_pytest_gpu.txt')):
+    f = glob.glob(os.path.join(src, pat), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(dst, name))
+print('wrote profiles/%s_*' % tag)
