@@ -368,8 +368,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
       const ddp_layer_weights& lw = w->layers[l];
       DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
       DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
-      DDP_TRY(launch_msda_gather(o.v, o.samp, o.s, M, o.Nh, o.hh, o.wh, st));
-      DDP_TRY(launch_row_to_sb(o.s, 256, o.s_sb, M, 256, st));
+      DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
       DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
                                       o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));
       const float* a = aff + size_t(l) * 512;

@@ -70,6 +70,8 @@ int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st)
 int launch_fold_affine(const float* gamma, const float* beta, const float* film, float* out, int count, hipStream_t st);
 int launch_msda_gather(const float* value, const float* samp, float* out, int rows, int n_tok, int h, int w,
                        hipStream_t st);
+int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
+                          hipStream_t st);
 int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);
 // y[s][o] = out_act( W[o][:] . in_act(x[s][:]) + b[o] )   act: 0 none, 1 gelu(out), 2 silu(in)
 int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,

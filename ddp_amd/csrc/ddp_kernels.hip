@@ -177,6 +177,87 @@ __global__ void __launch_bounds__(256) k_msda_gather(const float* __restrict__ v
   *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + hd * 32 + cq) = acc;
 }
 
+// Same gather, output written as SB (the split fragment-major A operand of output_proj): a block owns one
+// 32-token group, each wave gathers 8 of its tokens into a padded fp32 LDS tile (row stride 260 dwords: a
+// ds_read_b128 lane group of 16 tokens hits 16 distinct 4-bank sets), then the block emits the group's
+// 16 K16-blocks x 3 pieces x 64 lanes as fully coalesced 16-B stores.  Replaces gather + k_row_to_sb
+// (saves a 1 KiB write + 1 KiB read per token and a launch).
+constexpr int GSB_LD = 260;
+__global__ void __launch_bounds__(256) k_msda_gather_sb(const float* __restrict__ value, const float* __restrict__ samp,
+                                                         unsigned short* __restrict__ out_sb, int rows, int n_tok, int h,
+                                                         int w) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int hd = lane >> 3;
+  const int cq = (lane & 7) * 4;
+  const int m_base = blockIdx.x * 32;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int jj = wave * 8 + it;
+    const int m = m_base + jj;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (m < rows) {
+      const float* vbase = value + size_t(m / n_tok) * n_tok * 256 + hd * 32 + cq;
+      const float* sp = samp + size_t(m) * DDP_SAMP_STRIDE;
+      const f32x4 c01 = *reinterpret_cast<const f32x4*>(sp + hd * 8);
+      const f32x4 c23 = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
+      const f32x4 aw = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+      const float xs[4] = {c01[0], c01[2], c23[0], c23[2]};
+      const float ys[4] = {c01[1], c01[3], c23[1], c23[3]};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float x = xs[p], y = ys[p];
+        const float xf = floorf(x), yf = floorf(y);
+        const float fx = x - xf, fy = y - yf;
+        const int x0 = int(xf), y0 = int(yf);
+        const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x0 + 1 >= 0) & (x0 + 1 < w);
+        const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y0 + 1 >= 0) & (y0 + 1 < h);
+        const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1);
+        const int yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
+        const float w00 = (vx0 & vy0) ? (1.f - fy) * (1.f - fx) : 0.f;
+        const float w01 = (vx1 & vy0) ? (1.f - fy) * fx : 0.f;
+        const float w10 = (vx0 & vy1) ? fy * (1.f - fx) : 0.f;
+        const float w11 = (vx1 & vy1) ? fy * fx : 0.f;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc0 * w + xc0) * 256);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc0 * w + xc1) * 256);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc1 * w + xc0) * 256);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(vbase + size_t(yc1 * w + xc1) * 256);
+        const f32x4 sv = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        acc += sv * aw[p];
+      }
+    }
+    *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + hd * 32 + cq) = acc;
+  }
+  __syncthreads();
+  char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 256 * 192;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int item = r * 256 + threadIdx.x;        // (b, lane') with lane' = (h', j)
+    const int b = item >> 6, l2 = item & 63;
+    const int j = l2 & 31, hh = l2 >> 5;
+    const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
+    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
+    unsigned short p[3][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      split3(lo4[u], p[0][u], p[1][u], p[2][u]);
+      split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
+    }
+    char* base = gbase + size_t(b) * 3 * 1024 + l2 * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uint4 v;
+      v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+      v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+      v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+      v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+      *reinterpret_cast<uint4*>(base + c * 1024) = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // time embedding pieces (segmentors/ddp.py:41-46,107-112; utils/transformer.py:275-278)
 // ------------------------------------------------------------------------------------------------
@@ -561,6 +642,11 @@ int launch_msda_gather(const float* value, const float* samp, float* out, int ro
                        hipStream_t st) {
   hipLaunchKernelGGL(k_msda_gather, dim3(cdiv(rows, 4)), dim3(256), 0, st, value, samp, out, rows, n_tok, h, w);
   return check_launch("k_msda_gather");
+}
+int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_msda_gather_sb, dim3(cdiv(rows, 32)), dim3(256), 0, st, value, samp, out_sb, rows, n_tok, h, w);
+  return check_launch("k_msda_gather_sb");
 }
 int launch_sinusoid(const float* freq, const float* t_in, int S, float* u, hipStream_t st) {
   hipLaunchKernelGGL(k_sinusoid, dim3(S), dim3(64), 0, st, freq, t_in, S, u);
