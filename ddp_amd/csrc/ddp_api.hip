@@ -369,12 +369,14 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
       DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
       DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
       DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
-      DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
-                                      o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));
       const float* a = aff + size_t(l) * 512;
       if (b3_ffn_fused_enabled()) {
-        DDP_TRY(launch_b3_ffn(o.q1_sb, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, a, a + 256, nullptr, o.q_sb, M, st));
+        // output_proj + LN0 + FFN + LN1 + FiLM in one kernel: q1 never leaves the registers
+        DDP_TRY(launch_b3_ffn(nullptr, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, a, a + 256, o.q_sb, M, st, o.s_sb, o.q_sb,
+                              &o.wp_o[l], lw.output_proj_b, lw.norm0_w, lw.norm0_b));
       } else {
+        DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
+                                        o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));
         DDP_TRY(launch_b3_linear_sb(o.q1_sb, o.wp_f0[l], lw.ffn0_b, nullptr, 0, 0, 0, o.h_sb, nullptr, M, DDP_FFN, 256, 1, st,
                                     TAG_FC1));
         DDP_TRY(launch_b3_linear_res_ln(o.h_sb, o.wp_f1[l], lw.ffn1_b, nullptr, o.q1_sb, a, a + 256, nullptr, o.q_sb, M,

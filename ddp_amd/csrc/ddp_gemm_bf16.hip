@@ -1,4 +1,6 @@
 // ddp_gemm_bf16.hip - launchers of the bf16x3-split ("fp32-equivalent") token GEMM (gemm_bf16x3.h).
+#include <cstring>
+
 #include "ddp_internal.h"
 #include <stdlib.h>
 
@@ -118,11 +120,32 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
   return launch_b3<3, TAG_SAMP>(ga, e, st);
 }
 
+namespace {
+template <bool OUTPROJ>
+int launch_ffn_t(const b3::FfnArgs& fa, const b3::EpiResLNSB& e, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN, OUTPROJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::FFN_LDS_B));
+    attr_done = true;
+  }
+  const int grid = (fa.M + b3::FFN_BM - 1) / b3::FFN_BM;
+  prof_begin(TAG_FC2_LN, st);
+  hipLaunchKernelGGL((b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN, OUTPROJ>), dim3(grid), dim3(b3::FFN_THREADS), b3::FFN_LDS_B, st,
+                     fa, e);
+  prof_end(TAG_FC2_LN, st);
+  return check_launch("b3::k_ffn");
+}
+}  // namespace
+
+// out = FiLM(LN1(x + FFN(x))); x = X_sb, or - when S_sb is given - x = LN0(Q_sb + Wo . S_sb + bo) computed in-kernel
 int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
-                  hipStream_t st) {
+                  const float* ga_aff, const float* be_aff, unsigned short* out_sb, int M, hipStream_t st,
+                  const unsigned short* S_sb, const unsigned short* Q_sb, const SplitW* wo, const float* bo,
+                  const float* ga0, const float* be0) {
   if (M <= 0) return DDP_OK;
   b3::FfnArgs fa;
+  memset(&fa, 0, sizeof(fa));
   fa.X = X_sb;
   fa.W1p = w1.p;
   fa.W2p = w2.p;
@@ -130,23 +153,22 @@ int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2
   fa.b2 = b2;
   fa.M = M;
   b3::EpiResLNSB e;
-  e.res = nullptr;      // the residual is the kernel's own input: rebuilt from the resident fragments
+  e.res = nullptr;      // the residual is the kernel's own input
   e.res_sb = nullptr;
   e.ga = ga_aff;
   e.be = be_aff;
-  e.out_f32 = out_f32_blk;
+  e.out_f32 = nullptr;
   e.out_sb = out_sb;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::FFN_LDS_B));
-    attr_done = true;
+  if (S_sb) {
+    fa.S = S_sb;
+    fa.Q = Q_sb;
+    fa.Wop = wo->p;
+    fa.bo = bo;
+    fa.ga0 = ga0;
+    fa.be0 = be0;
+    return launch_ffn_t<true>(fa, e, st);
   }
-  const int grid = (M + b3::FFN_BM - 1) / b3::FFN_BM;
-  prof_begin(TAG_FC2_LN, st);
-  hipLaunchKernelGGL((b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN>), dim3(grid), dim3(b3::FFN_THREADS), b3::FFN_LDS_B, st, fa, e);
-  prof_end(TAG_FC2_LN, st);
-  return check_launch("b3::k_ffn");
+  return launch_ffn_t<false>(fa, e, st);
 }
 
 bool b3_ffn_fused_enabled() {

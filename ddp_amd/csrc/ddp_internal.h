@@ -54,8 +54,9 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
                           int w, float* out, int M, hipStream_t st);
 // whole FFN block (fc1 + GELU + fc2 + residual + LayerNorm + FiLM) in one kernel (ffn_bf16x3.h)
 int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* ga_aff, const float* be_aff, float* out_f32_blk, unsigned short* out_sb, int M,
-                  hipStream_t st);
+                  const float* ga_aff, const float* be_aff, unsigned short* out_sb, int M, hipStream_t st,
+                  const unsigned short* S_sb = nullptr, const unsigned short* Q_sb = nullptr, const SplitW* wo = nullptr,
+                  const float* bo = nullptr, const float* ga0 = nullptr, const float* be0 = nullptr);
 bool b3_ffn_fused_enabled();
 // W fp32 (rows, ld) -> Wp[3][rows][K]
 int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);
