@@ -85,6 +85,8 @@ struct Layout {
   SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
       wp_f1[DDP_MAX_LAYERS];
   unsigned short *q_sb, *q1_sb, *s_sb, *h_sb, *in_sb;   // in_sb: mask / x / feat staging (row-major producers)
+  unsigned char* wstream[DDP_MAX_LAYERS];               // layer kernel: weight stream (stage images) per layer
+  float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
   size_t total;
 };
 
@@ -221,6 +223,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
       o->wp_o[l] = takew(256, 256);
       o->wp_f0[l] = takew(DDP_FFN, 256);
       o->wp_f1[l] = takew(256, DDP_FFN);
+      o->wstream[l] = reinterpret_cast<unsigned char*>(cv.take(b3_layer_stream_bytes() / sizeof(float)));
+      o->bias_ext[l] = cv.take(size_t(b3_layer_bias_floats()));
     }
     auto takesb = [&](size_t rows, size_t C) {       // SB: 6 bytes per element, rows padded to 256
       const size_t rp = (rows + 255) / 256 * 256;
@@ -348,6 +352,29 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       DDP_TRY(launch_split_weights(lw.ffn0_w, 256, DDP_FFN, 256, wr(o.wp_f0[l]), st));
       DDP_TRY(launch_split_weights(lw.ffn1_w, DDP_FFN, 256, DDP_FFN, wr(o.wp_f1[l]), st));
     }
+    // layer-kernel weight streams: [Wo: 8 wide stages][16 x (fc1 tall, tall, fc2 wide, wide)][next Wv: 8 tall][next Wcat: 4 tall]
+    for (int l = 0; l < o.L; ++l) {
+      const ddp_layer_weights& lw = w->layers[l];
+      unsigned char* sp = o.wstream[l];
+      DDP_TRY(launch_build_stages(o.wp_o[l].p, o.wp_o[l].comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, sp, st));
+      DDP_TRY(launch_build_stages(o.wp_f0[l].p, o.wp_f0[l].comp_stride, 256, DDP_FFN, 1, 16, 2, 8, 0, 1, 4, sp, st));
+      DDP_TRY(launch_build_stages(o.wp_f1[l].p, o.wp_f1[l].comp_stride, DDP_FFN, 256, 0, 1, 32, 10, 4, 1, 0, sp, st));
+      if (hipMemsetAsync(o.bias_ext[l], 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          hipMemcpyAsync(o.bias_ext[l], lw.ffn0_b, DDP_FFN * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("bias table copy failed");
+        return DDP_E_LAUNCH;
+      }
+      if (l + 1 < o.L) {
+        const ddp_layer_weights& nw = w->layers[l + 1];
+        DDP_TRY(launch_build_stages(o.wp_v[l + 1].p, o.wp_v[l + 1].comp_stride, 256, 256, 1, 4, 2, 72, 0, 1, 2, sp, st));
+        DDP_TRY(launch_build_stages(o.wp_cat[l + 1].p, o.wp_cat[l + 1].comp_stride, 256, 96, 1, 2, 2, 80, 0, 1, 2, sp, st));
+        if (hipMemcpyAsync(o.bias_ext[l] + DDP_FFN, nw.value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+            hipSuccess) {
+          set_error("bias table copy failed");
+          return DDP_E_LAUNCH;
+        }
+      }
+    }
   }
   return DDP_OK;
 }
@@ -364,16 +391,37 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
     // of an element sum to its fp32 value exactly)
+    const bool fused = b3_layer_fused_enabled();
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
-      DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
-      DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
+      if (l == 0 || !fused) {       // later layers: emitted by the previous layer kernel
+        DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
+        DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
+      }
       DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
       const float* a = aff + size_t(l) * 512;
-      if (b3_ffn_fused_enabled()) {
-        // output_proj + LN0 + FFN + LN1 + FiLM in one kernel: q1 never leaves the registers
-        DDP_TRY(launch_b3_ffn(nullptr, o.wp_f0[l], o.wp_f1[l], lw.ffn0_b, lw.ffn1_b, a, a + 256, o.q_sb, M, st, o.s_sb, o.q_sb,
-                              &o.wp_o[l], lw.output_proj_b, lw.norm0_w, lw.norm0_b));
+      if (fused) {
+        // output_proj + LN0 + FFN + LN1 + FiLM + the next layer's value / sampling projections: one persistent kernel
+        LayerLaunch ll;
+        ll.S = o.s_sb;
+        ll.Q = o.q_sb;
+        ll.stream = o.wstream[l];
+        ll.bias_ext = o.bias_ext[l];
+        ll.bo = lw.output_proj_b;
+        ll.ga0 = lw.norm0_w;
+        ll.be0 = lw.norm0_b;
+        ll.b2 = lw.ffn1_b;
+        ll.ga1 = a;
+        ll.be1 = a + 256;
+        ll.M = M;
+        ll.has_next = l + 1 < o.L;
+        ll.v_out = o.v;
+        ll.samp_out = o.samp;
+        ll.py = ll.has_next ? o.py[l + 1] : nullptr;
+        ll.px = ll.has_next ? o.px[l + 1] : nullptr;
+        ll.n_tok = o.Nh;
+        ll.w = o.wh;
+        DDP_TRY(launch_b3_layer(ll, st));
       } else {
         DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
                                         o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));

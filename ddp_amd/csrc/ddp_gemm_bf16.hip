@@ -4,7 +4,7 @@
 #include "ddp_internal.h"
 #include <stdlib.h>
 
-#include "ffn_bf16x3.h"
+#include "layer_bf16x3.h"
 #include "gemm_bf16x3.h"
 
 namespace ddp {
@@ -120,61 +120,49 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
   return launch_b3<3, TAG_SAMP>(ga, e, st);
 }
 
-namespace {
-template <bool OUTPROJ>
-int launch_ffn_t(const b3::FfnArgs& fa, const b3::EpiResLNSB& e, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN, OUTPROJ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::FFN_LDS_B));
-    attr_done = true;
+int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
+  if (a.M <= 0) return DDP_OK;
+  b3::LayerArgs la;
+  la.S = a.S;
+  la.Q = a.Q;
+  la.stream = a.stream;
+  la.bias_ext = a.bias_ext;
+  la.bo = a.bo;
+  la.ga0 = a.ga0;
+  la.be0 = a.be0;
+  la.b2 = a.b2;
+  la.ga1 = a.ga1;
+  la.be1 = a.be1;
+  la.M = a.M;
+  la.has_next = a.has_next;
+  la.v_out = a.v_out;
+  la.samp_out = a.samp_out;
+  la.py = a.py;
+  la.px = a.px;
+  la.n_tok = a.n_tok;
+  la.w = a.w;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(b3::LYR_LDS_B));
   }
-  const int grid = (fa.M + b3::FFN_BM - 1) / b3::FFN_BM;
+  const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;       // persistent: one block per CU walks tiles blockIdx, +grid, ...
   prof_begin(TAG_FC2_LN, st);
-  hipLaunchKernelGGL((b3::k_ffn<b3::EpiResLNSB, TAG_FC2_LN, OUTPROJ>), dim3(grid), dim3(b3::FFN_THREADS), b3::FFN_LDS_B, st,
-                     fa, e);
+  hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
   prof_end(TAG_FC2_LN, st);
-  return check_launch("b3::k_ffn");
+  return check_launch("b3::k_layer");
 }
-}  // namespace
+size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }
+int b3_layer_bias_floats() { return b3::LYR_BIAS_N; }
 
-// out = FiLM(LN1(x + FFN(x))); x = X_sb, or - when S_sb is given - x = LN0(Q_sb + Wo . S_sb + bo) computed in-kernel
-int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* ga_aff, const float* be_aff, unsigned short* out_sb, int M, hipStream_t st,
-                  const unsigned short* S_sb, const unsigned short* Q_sb, const SplitW* wo, const float* bo,
-                  const float* ga0, const float* be0) {
-  if (M <= 0) return DDP_OK;
-  b3::FfnArgs fa;
-  memset(&fa, 0, sizeof(fa));
-  fa.X = X_sb;
-  fa.W1p = w1.p;
-  fa.W2p = w2.p;
-  fa.b1 = b1;
-  fa.b2 = b2;
-  fa.M = M;
-  b3::EpiResLNSB e;
-  e.res = nullptr;      // the residual is the kernel's own input
-  e.res_sb = nullptr;
-  e.ga = ga_aff;
-  e.be = be_aff;
-  e.out_f32 = nullptr;
-  e.out_sb = out_sb;
-  if (S_sb) {
-    fa.S = S_sb;
-    fa.Q = Q_sb;
-    fa.Wop = wo->p;
-    fa.bo = bo;
-    fa.ga0 = ga0;
-    fa.be0 = be0;
-    return launch_ffn_t<true>(fa, e, st);
-  }
-  return launch_ffn_t<false>(fa, e, st);
-}
-
-bool b3_ffn_fused_enabled() {
+bool b3_layer_fused_enabled() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("DDP_FFN_FUSED");
+    const char* e = getenv("DDP_LAYER_FUSED");
     v = e ? atoi(e) : 1;
   }
   return v != 0;

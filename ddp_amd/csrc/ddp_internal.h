@@ -53,11 +53,25 @@ int launch_b3_linear_res_ln(const unsigned short* A_sb, const SplitW& w, const f
 int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const float* py, const float* px, int n_tok,
                           int w, float* out, int M, hipStream_t st);
 // whole FFN block (fc1 + GELU + fc2 + residual + LayerNorm + FiLM) in one kernel (ffn_bf16x3.h)
-int launch_b3_ffn(const unsigned short* X_sb, const SplitW& w1, const SplitW& w2, const float* b1, const float* b2,
-                  const float* ga_aff, const float* be_aff, unsigned short* out_sb, int M, hipStream_t st,
-                  const unsigned short* S_sb = nullptr, const unsigned short* Q_sb = nullptr, const SplitW* wo = nullptr,
-                  const float* bo = nullptr, const float* ga0 = nullptr, const float* be0 = nullptr);
-bool b3_ffn_fused_enabled();
+// layer kernel (layer_bf16x3.h): weight stream builder + launcher
+int launch_build_stages(const unsigned short* Wp, size_t comp_stride, int K, int rows_valid, int tall, int n_rowblk, int n_kblk,
+                        int base, int a, int b, int c, unsigned char* stream, hipStream_t st);
+struct LayerLaunch {
+  const unsigned short* S;
+  unsigned short* Q;
+  const unsigned char* stream;
+  const float* bias_ext;
+  const float *bo, *ga0, *be0, *b2, *ga1, *be1;
+  int M, has_next;
+  float* v_out;
+  float* samp_out;
+  const float *py, *px;
+  int n_tok, w;
+};
+int launch_b3_layer(const LayerLaunch& a, hipStream_t st);
+size_t b3_layer_stream_bytes();
+int b3_layer_bias_floats();
+bool b3_layer_fused_enabled();
 // W fp32 (rows, ld) -> Wp[3][rows][K]
 int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);
 // fp32 row-major (rows, C) ld -> SB

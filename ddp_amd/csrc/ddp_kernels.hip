@@ -92,6 +92,34 @@ __global__ void k_split_weights(const float* __restrict__ W, int ld, int rows, i
   }
 }
 
+// Stage images of the layer kernel's weight stream (layer_bf16x3.h): one 48 KiB image per (row block, k block) of a
+// split weight matrix, byte-for-byte what the LDS ring slot holds ([piece 3][row][16-B slot], slots XOR-swizzled).
+//   tall = 1: 64 rows x 128 k, 16 slots per row, slot = chunk ^ (row & 15)
+//   tall = 0: 256 rows x 32 k,  4 slots per row, slot = chunk ^ ((row >> 2) & 3)
+// image index = base + rowblk*c + (kblk>>1)*a + (kblk&1)*b; rows >= rows_valid are zero.
+__global__ void __launch_bounds__(256) k_build_stages(const unsigned short* __restrict__ Wp, size_t comp_stride, int K,
+                                                       int rows_valid, int tall, int n_kblk, int base, int a, int b, int c,
+                                                       unsigned char* __restrict__ stream) {
+  const int st = blockIdx.y;                     // (rowblk, kblk)
+  const int rowblk = st / n_kblk, kblk = st - rowblk * n_kblk;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // 16-B chunk of the image: 3072 per stage
+  if (idx >= 3072) return;
+  const int comp = idx >> 10, rem = idx & 1023;
+  int row, chunk, slot, rows_per, k_per;
+  if (tall) {
+    row = rem >> 4; chunk = rem & 15; slot = chunk ^ (row & 15); rows_per = 64; k_per = 128;
+  } else {
+    row = rem >> 2; chunk = rem & 3; slot = chunk ^ ((row >> 2) & 3); rows_per = 256; k_per = 32;
+  }
+  const int grow = rowblk * rows_per + row;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (grow < rows_valid)
+    v = *reinterpret_cast<const uint4*>(Wp + size_t(comp) * comp_stride + size_t(grow) * K + kblk * k_per + 8 * chunk);
+  const int image = base + rowblk * c + (kblk >> 1) * a + (kblk & 1) * b;
+  const int per_row = tall ? 16 : 4;
+  *reinterpret_cast<uint4*>(stream + size_t(image) * 49152 + comp * 16384 + (row * per_row + slot) * 16) = v;
+}
+
 // fp32 row-major (rows, C) -> SB: one half-wave per token, lane (b, h) handles the 8 channels of its slot
 __global__ void __launch_bounds__(256) k_row_to_sb(const float* __restrict__ in, int ld, unsigned short* __restrict__ out,
                                                     int rows, int C) {
@@ -623,6 +651,12 @@ int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short
   const long n = long(rows) * (K / 8);
   hipLaunchKernelGGL(k_split_weights, dim3(cdiv(n, 256)), dim3(256), 0, st, W, ld, rows, K, out);
   return check_launch("k_split_weights");
+}
+int launch_build_stages(const unsigned short* Wp, size_t comp_stride, int K, int rows_valid, int tall, int n_rowblk, int n_kblk,
+                        int base, int a, int b, int c, unsigned char* stream, hipStream_t st) {
+  hipLaunchKernelGGL(k_build_stages, dim3(12, n_rowblk * n_kblk), dim3(256), 0, st, Wp, comp_stride, K, rows_valid, tall,
+                     n_kblk, base, a, b, c, stream);
+  return check_launch("k_build_stages");
 }
 int launch_row_to_sb(const float* in, int ld, unsigned short* out_sb, int rows, int C, hipStream_t st) {
   const long n = long(rows) * (C / 8);

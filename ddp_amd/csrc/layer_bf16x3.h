@@ -1,0 +1,522 @@
+// layer_bf16x3.h - everything of a decoder layer that follows the deformable gather, in ONE persistent kernel
+// (bf16x3-split arithmetic, see gemm_bf16x3.h):
+//
+//     x   = LayerNorm0( q + Wo . s + bo )                                  output_proj + identity + norms.0
+//     q'  = FiLM( LayerNorm1( x + W2 . GELU(W1 . x + b1) + b2 ) )          FFN + identity + norms.1 + time FiLM
+//     v'  = Wv' . q' + bv' ;  samp' = softmax4/pixel-coords( Wcat' . q' + pos' )   NEXT layer's projections
+//
+// (utils/transformer.py:352-358,390-392,413-417; mmcv FFN transformer.py:269-280; multi_scale_deform_attn.py:313-334)
+//
+// Why one kernel.  With the 2.65x faster bf16x3 contractions the layer was HBM bound; every tensor between these
+// GEMMs (q1, the 1024-wide hidden activation, and q' as the operand of the next projections) now stays in the
+// register file.  Per token the kernel reads s (1.5 KiB) + q (1.5 KiB) and writes q' (1.5 KiB) + v' (1 KiB) +
+// samp' (0.4 KiB).
+//
+//   * a wave owns 32 tokens; the block's 4 waves (one per SIMD, 512 registers each) share the weight stream;
+//   * an accumulator lane (token j, half h) holds channels 32t + 8g + 4h + e, and the k-slots of an MFMA B operand
+//     may be ANY fixed permutation of K shared with the (pre-permuted) weights, so "split the accumulator into
+//     three bf16 pieces" IS "build the B fragment of the next contraction": LayerNorm0's output feeds fc1,
+//     GELU(fc1) feeds fc2, LayerNorm1's output feeds the next layer's projections - no LDS round trip, no shuffle;
+//   * ALL weights of the kernel are one linear STREAM of 48 KiB stage images (already in the swizzled LDS layout,
+//     built once by k_build_stages) in the order they are consumed: 8 output_proj stages, 16 x (2 fc1 + 2 fc2)
+//     stages, 8 + 4 stages of the next layer's projections.  A 3-slot LDS ring runs two stages ahead by LDS-DMA;
+//     every piece is "1 KiB from stream + off to ring + off", so four pieces share one M0 / one base (the
+//     instruction's immediate offset moves BOTH sides - scripts/ubench/lds_dma_off.hip) and the stream simply wraps
+//     to the next token tile: the ring never drains between tiles (persistent blocks).
+// One-wave-per-SIMD scheduling rules (MI355X_MICROARCH.md latency table; each one measured here):
+//   * two accumulator chains are always interleaved - a dependent MFMA right behind its producer is free only when
+//     NOTHING is issued between them, and loads / GELU / DMA have to sit somewhere;
+//   * a weight fragment is re-read into its own registers as soon as its last MFMA of the block has issued
+//     (w2 after 2 MFMAs, w1 after 6, w0 after 12 - terms ordered for that), >= 6 MFMAs before its next use;
+//   * the 12 DMA pieces of a stage are spread over its 8 MFMA blocks; GELU of k-block n+1 runs under k-block n.
+#pragma once
+#include <type_traits>
+
+#include "gemm_bf16x3.h"
+
+namespace ddp {
+namespace b3 {
+
+constexpr int LYR_BM = 128;
+constexpr int LYR_THREADS = 256;
+constexpr int LYR_STAGE_B = 48 * 1024;
+constexpr int LYR_RING = 3;                                   // stages in flight: compute q, landed q+1, landing q+2
+constexpr int LYR_BIAS_OFF = LYR_RING * LYR_STAGE_B;
+constexpr int LYR_BIAS_N = 1024 + 256 + 128;                  // fc1 bias | next value_proj bias | zeros (sampling proj)
+// per-channel vectors kept in LDS behind the bias table (their pointers die after the kernel prologue)
+constexpr int LYR_T_BO = LYR_BIAS_N, LYR_T_GA0 = LYR_T_BO + 256, LYR_T_BE0 = LYR_T_GA0 + 256, LYR_T_B2 = LYR_T_BE0 + 256,
+              LYR_T_GA1 = LYR_T_B2 + 256, LYR_T_BE1 = LYR_T_GA1 + 256, LYR_TABLE_N = LYR_T_BE1 + 256;
+constexpr size_t LYR_LDS_B = size_t(LYR_BIAS_OFF) + LYR_TABLE_N * 4;
+constexpr int LYR_ST_OUT = 8, LYR_ST_FFN = 64, LYR_ST_NEXT = 12;
+constexpr int LYR_STAGES = LYR_ST_OUT + LYR_ST_FFN + LYR_ST_NEXT;
+
+struct LayerArgs {
+  const unsigned short* S;       // SB attention output (A operand of output_proj)
+  unsigned short* Q;             // SB layer input (residual) -> layer output, in place (a block touches only its tokens)
+  const unsigned char* stream;   // LYR_STAGES stage images
+  const float* bias_ext;         // (LYR_BIAS_N)
+  const float* bo;               // output_proj bias (256)
+  const float* ga0;              // norms.0 weight / bias
+  const float* be0;
+  const float* b2;               // fc2 bias
+  const float* ga1;              // norms.1 affine x FiLM (folded)
+  const float* be1;
+  int M;
+  int has_next;                  // also emit the next layer's value / sampling projections
+  float* v_out;                  // (M,256) row-major fp32
+  float* samp_out;               // (M,96): 64 pixel coordinates + 32 attention weights
+  const float* py;               // next layer's positional tables (h,96) / (w,96), bias folded in
+  const float* px;
+  int n_tok, w;
+};
+
+// vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
+__device__ __forceinline__ void wait_vm12() { __builtin_amdgcn_s_waitcnt(0x0F7C); }
+
+// element u (0..7) of a packed bf16x8 fragment as fp32
+__device__ __forceinline__ float bf_elem(const u32x4& v, int u) {
+  const unsigned w = v[u >> 1];
+  return __uint_as_float((u & 1) ? (w & 0xFFFF0000u) : (w << 16));
+}
+
+// one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + lane*16 + IMM) -> LDS (m0v + lane*16 + IMM)
+template <int IMM>
+__device__ __forceinline__ void stream_piece(const unsigned char* base, unsigned voff, unsigned m0v) {
+  // the operands are wave-uniform by construction; readfirstlane only tells the compiler so ("s" needs an SGPR)
+  const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b64)), hi = __builtin_amdgcn_readfirstlane(unsigned(b64 >> 32));
+  const unsigned long long bu = (static_cast<unsigned long long>(hi) << 32) | lo;
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:%3"
+      :
+      : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(m0v)), "n"(IMM)
+      : "memory");
+}
+
+template <int TAG>
+__global__ void __launch_bounds__(LYR_THREADS, 1)
+k_layer(LayerArgs la) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const int M = la.M;
+  const int ntiles = (M + LYR_BM - 1) / LYR_BM;
+  if (int(blockIdx.x) >= ntiles) return;
+  const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
+  const unsigned voff = unsigned(lane * 16);
+  const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
+  const unsigned char* const s_begin = la.stream;
+  const unsigned char* const s_end = la.stream + size_t(la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN) * LYR_STAGE_B;
+  const unsigned char* nptr = s_begin;                         // next stage image to fetch
+  auto nxt = [](int s) { return s == LYR_RING - 1 ? 0 : s + 1; };
+
+  // pieces [i0, i1) of stage image *nptr into ring slot `dslot`
+  auto dma = [&](int dslot, int i0, int i1) __attribute__((always_inline)) {
+    const unsigned char* nb = nptr + wave_off;
+    const unsigned mb = lds0 + unsigned(dslot * LYR_STAGE_B) + wave_off;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      if (i < i0 || i >= i1) continue;
+      const int g = i >> 2;
+      switch (i & 3) {
+        case 0: stream_piece<0>(nb + g * 4096, voff, mb + g * 4096); break;
+        case 1: stream_piece<1024>(nb + g * 4096, voff, mb + g * 4096); break;
+        case 2: stream_piece<2048>(nb + g * 4096, voff, mb + g * 4096); break;
+        default: stream_piece<3072>(nb + g * 4096, voff, mb + g * 4096); break;
+      }
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    nptr += LYR_STAGE_B;
+    nptr = nptr == s_end ? s_begin : nptr;
+  };
+
+  // fragment reads (per-lane base + slot base + compile-time offsets)
+  const char* lbase = reinterpret_cast<const char*>(smem);
+  const int f1_lane = j * 256;      // "tall" stage [64 rows x 128 k]: row t*32+j, 16 slots of 16 B, swizzle (row & 15)
+  const int f2_lane = j * 64;       // "wide" stage [256 rows x 32 k]: row t*32+j, 4 slots, swizzle ((row>>2) & 3)
+  auto frag1 = [&](int slot, int comp, int t, int b) -> u32x4 {      // K16 step b (0..7)
+    return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 8192 + f1_lane + (((2 * b + h) ^ (j & 15)) << 4));
+  };
+  auto frag2 = [&](int slot, int comp, int t, int ks) -> u32x4 {     // K16 step ks (0..1)
+    return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
+  };
+
+#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, RELOAD2, RELOAD1, RELOAD0, FILL1, FILL0)                                   \
+  A0 = mma(w[0][2], X0, A0);                                                                                        \
+  A1 = mma(w[1][2], X0, A1);                                                                                        \
+  RELOAD2;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  A0 = mma(w[0][1], X1, A0);                                                                                        \
+  A1 = mma(w[1][1], X1, A1);                                                                                        \
+  A0 = mma(w[0][1], X0, A0);                                                                                        \
+  A1 = mma(w[1][1], X0, A1);                                                                                        \
+  FILL1;                                                                                                            \
+  RELOAD1;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  A0 = mma(w[0][0], X2, A0);                                                                                        \
+  A1 = mma(w[1][0], X2, A1);                                                                                        \
+  A0 = mma(w[0][0], X1, A0);                                                                                        \
+  A1 = mma(w[1][0], X1, A1);                                                                                        \
+  A0 = mma(w[0][0], X0, A0);                                                                                        \
+  A1 = mma(w[1][0], X0, A1);                                                                                        \
+  FILL0;                                                                                                            \
+  RELOAD0;                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- kernel prologue: first two stages of the stream, bias table -> LDS
+  int slot = 0;
+  dma(0, 0, 12);
+  advance();
+  dma(1, 0, 12);
+  advance();
+  {
+    float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + LYR_BIAS_OFF);
+    for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
+    tab[LYR_T_BO + tid] = la.bo[tid];
+    tab[LYR_T_GA0 + tid] = la.ga0[tid];
+    tab[LYR_T_BE0 + tid] = la.be0[tid];
+    tab[LYR_T_B2 + tid] = la.b2[tid];
+    tab[LYR_T_GA1 + tid] = la.ga1[tid];
+    tab[LYR_T_BE1 + tid] = la.be1[tid];
+  }
+  wait_vm0();
+  __syncthreads();
+  const float* bias_s0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + LYR_BIAS_OFF);
+  const float* bias_s = bias_s0;
+
+  u32x4 xa[16][3];
+  f32x16 acc2[8];
+  int ht = h;
+
+  // acc (+)= W[64 rows x 256 k] . xa over two "tall" stages; the ring's look-ahead is fetched on the way
+  auto tall_stage = [&](f32x16& a0, f32x16& a1, int s1) __attribute__((always_inline)) {
+    const int dslot = nxt(nxt(slot));
+    u32x4 w[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[t][c] = frag1(slot, c, t, 0);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool nb = b + 1 < 8;
+      if (s1 == 0) {
+        DDP_LYR_BLOCK(a0, a1, xa[b][0], xa[b][1], xa[b][2],
+                      if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
+                      if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
+                      if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); },
+                      dma(dslot, b, b + 1),
+                      if (b < 4) dma(dslot, 8 + b, 9 + b))
+      } else {
+        DDP_LYR_BLOCK(a0, a1, xa[8 + b][0], xa[8 + b][1], xa[8 + b][2],
+                      if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
+                      if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
+                      if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); },
+                      dma(dslot, b, b + 1),
+                      if (b < 4) dma(dslot, 8 + b, 9 + b))
+      }
+    }
+    advance();
+    wait_vm12();
+    __syncthreads();
+    slot = nxt(slot);
+  };
+  auto bias_init = [&](f32x16 (&a)[2], int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + chunk * 64 + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[t][4 * g + e] = b[e];
+      }
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t grp = size_t(tile) * (LYR_BM / 32) + wave;    // this wave's 32-token group
+    // opaque per tile: otherwise the (tile-invariant) reads of the per-channel table are hoisted out of the tile
+    // loop - ~800 values per lane - and spilled to scratch
+    {
+      unsigned tab_off = LYR_BIAS_OFF;
+      asm volatile("" : "+v"(tab_off));
+      bias_s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + tab_off);
+    }
+    ht = h;                                                    // same for the lane's table index
+    asm volatile("" : "+v"(ht));
+    const int m_base = tile * LYR_BM + wave * 32;
+    const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
+    char* qs = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
+
+    // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead)
+    u32x4 sc[2][3], sn[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sc[ks][c] = *reinterpret_cast<const u32x4*>(ss + (ks * 3 + c) * 1024);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
+      }
+    auto p0_stage = [&](int st) __attribute__((always_inline)) {
+      const int dslot = nxt(nxt(slot));
+      const int stn = st + 1 < 8 ? st + 1 : 7;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
+      u32x4 w[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+          const int blk = ks * 4 + tp;
+          const bool nb = blk + 1 < 8;
+          const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+          DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2],
+                        if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
+                        if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
+                        if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
+                        dma(dslot, blk, blk + 1),
+                        if (blk < 4) dma(dslot, 8 + blk, 9 + blk))
+        }
+      advance();
+      wait_vm12();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          asm volatile("" : "+v"(sn[ks][c]));
+          sc[ks][c] = sn[ks][c];
+        }
+      __syncthreads();
+      slot = nxt(slot);
+    };
+    for (int st = 0; st < 6; ++st) p0_stage(st);
+    // residual fragments: fetched under the last two stages
+    u32x4 qa[16][3];
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+    p0_stage(6);
+    p0_stage(7);
+
+    // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = 2 * t + (r >> 3), u = r & 7;
+          const float v = acc2[t][r] + ((bf_elem(qa[b][0], u) + bf_elem(qa[b][1], u)) + bf_elem(qa[b][2], u));
+          acc2[t][r] = v;
+          sum += v;
+        }
+      const float mean = half_sum(sum) * (1.0f / 256.0f);
+      float var = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc2[t][r] - mean;
+          acc2[t][r] = d;
+          var += d * d;
+        }
+      const float rstd = 1.0f / sqrtf(half_sum(var) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = t * 32 + 8 * g + 4 * ht;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_GA0 + ch);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BE0 + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = acc2[t][4 * g + e] * (rstd * ga[e]) + be[e];
+        }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
+          split8(xv, xa[2 * t + gp][0], xa[2 * t + gp][1], xa[2 * t + gp][2]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_B2 + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] += b[e];
+        }
+      }
+    }
+
+    // ---- P2: FFN, 64 hidden channels at a time: acc1 = b1 + W1[chunk] . x; h = GELU(acc1); acc2 += W2[:, chunk] . h
+    for (int hc = 0; hc < 16; ++hc) {
+      f32x16 acc1[2];
+      bias_init(acc1, hc);
+      tall_stage(acc1[0], acc1[1], 0);
+      tall_stage(acc1[0], acc1[1], 1);
+      // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2));
+      // block 0 here, block kb+1 under block kb's MFMAs
+      u32x4 hcur[3];
+      float xg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xg[e] = gelu_fast(acc1[0][e]);
+      split8(xg, hcur[0], hcur[1], hcur[2]);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int dslot = nxt(nxt(slot));
+        u32x4 w[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kb = s2 * 2 + ks;
+          const int kn = kb + 1;
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp) {
+            const int blk = ks * 4 + tp;
+            const bool nb = blk + 1 < 8;
+            const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+            DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2],
+                          if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
+                          if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
+                          if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
+                          {
+                            dma(dslot, blk, blk + 1);
+                            if (kb < 3) xg[2 * tp] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
+                          },
+                          {
+                            if (blk < 4) dma(dslot, 8 + blk, 9 + blk);
+                            if (kb < 3) xg[2 * tp + 1] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
+                          })
+          }
+          if (kb < 3) split8(xg, hcur[0], hcur[1], hcur[2]);
+        }
+        advance();
+        wait_vm12();
+        __syncthreads();
+        slot = nxt(slot);
+      }
+    }
+
+    // ---- LayerNorm1 x FiLM: q' -> HBM as SB, and -> registers as the B fragments of the next projections
+    {
+      // fresh base: otherwise the 48 64-bit addresses of the residual loads are kept (spilled) for these stores
+      char* qst = qs;
+      asm volatile("" : "+v"(qst));
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc2[t][r];
+      const float mean = half_sum(sum) * (1.0f / 256.0f);
+      float var = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc2[t][r] - mean;
+          acc2[t][r] = d;
+          var += d * d;
+        }
+      const float rstd = 1.0f / sqrtf(half_sum(var) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = t * 32 + 8 * g + 4 * ht;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_GA1 + ch);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BE1 + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = acc2[t][4 * g + e] * (rstd * ga[e]) + be[e];
+        }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int b = 2 * t + gp;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
+          split8(xv, xa[b][0], xa[b][1], xa[b][2]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qst + (b * 3 + c) * 1024) = xa[b][c];
+        }
+      }
+    }
+
+    // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
+    if (la.has_next) {
+      const int m = m_base + j;
+      const bool valid = m < M;
+      for (int vc = 0; vc < 4; ++vc) {
+        f32x16 a[2];
+        bias_init(a, 16 + vc);
+        tall_stage(a[0], a[1], 0);
+        tall_stage(a[0], a[1], 1);
+        if (valid) {
+          float* dst = la.v_out + size_t(m) * 256 + vc * 64 + 4 * h;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]};
+        }
+      }
+      const int mm = valid ? m : M - 1;
+      const int n = mm % la.n_tok;
+      const int pi = n / la.w;
+      const int pj = n - pi * la.w;
+      const float fi = float(pi), fj = float(pj);
+      for (int sc2 = 0; sc2 < 2; ++sc2) {
+        f32x16 a[2];
+        bias_init(a, 20 + sc2);
+        tall_stage(a[0], a[1], 0);
+        tall_stage(a[0], a[1], 1);
+        if (valid) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (sc2 == 1 && t == 1) continue;                 // columns 96..127 are padding
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int col = sc2 * 64 + t * 32 + 8 * g + 4 * h;
+              const f32x4 pos = *reinterpret_cast<const f32x4*>(la.py + pi * 96 + col) + *reinterpret_cast<const f32x4*>(la.px + pj * 96 + col);
+              f32x4 v = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]} + pos;
+              if (sc2 == 0) {                                  // sampling offsets -> pixel coordinates (x, y, x, y)
+                v[0] += fj; v[1] += fi; v[2] += fj; v[3] += fi;
+              } else {                                         // attention weights: softmax over the head's 4 points
+                const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - mx);
+                const float den = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] /= den;
+              }
+              *reinterpret_cast<f32x4*>(la.samp_out + size_t(m) * 96 + col) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+#undef DDP_LYR_BLOCK
+  wait_vm0();
+}
+
+}  // namespace b3
+}  // namespace ddp
