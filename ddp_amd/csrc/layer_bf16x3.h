@@ -79,6 +79,37 @@ __device__ __forceinline__ float bf_elem(const u32x4& v, int u) {
   return __uint_as_float((u & 1) ? (w & 0xFFFF0000u) : (w << 16));
 }
 
+// gelu_fast (gemm_f32.h) in two halves of ~7 instructions so that each fits a filler slot
+struct GeluHalf { float x, t, e; };
+__device__ __forceinline__ GeluHalf gelu_a(float x) {
+  GeluHalf g;
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  g.x = x;
+  g.t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  g.e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  return g;
+}
+__device__ __forceinline__ float gelu_b(const GeluHalf& g) {
+  float p = fmaf(1.061405429f, g.t, -1.453152027f);
+  p = fmaf(p, g.t, 1.421413741f);
+  p = fmaf(p, g.t, -0.284496736f);
+  p = fmaf(p, g.t, 0.254829592f);
+  p *= g.t;
+  const float erf_abs = fmaf(-p, g.e, 1.0f);
+  const float h = 0.5f * g.x;
+  return fmaf(copysignf(erf_abs, g.x), h, h);
+}
+// exact 3-way split of two fp32 values, packed as one dword per piece (element 2i in the low half)
+__device__ __forceinline__ void split2_pack(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
+  const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+  const unsigned m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
+  const unsigned l0 = __float_as_uint(r0 - __uint_as_float(m0)), l1 = __float_as_uint(r1 - __uint_as_float(m1));
+  p1 = __builtin_amdgcn_perm(h1, h0, 0x07060302);
+  p2 = __builtin_amdgcn_perm(m1, m0, 0x07060302);
+  p3 = __builtin_amdgcn_perm(l1, l0, 0x07060302);
+}
+
 // one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + lane*16 + IMM) -> LDS (m0v + lane*16 + IMM)
 template <int IMM>
 __device__ __forceinline__ void stream_piece(const unsigned char* base, unsigned voff, unsigned m0v) {
@@ -147,27 +178,36 @@ k_layer(LayerArgs la) {
     return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
   };
 
-#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, RELOAD2, RELOAD1, RELOAD0, FILL1, FILL0)                                   \
+  // One block = 12 MFMAs on a tile pair (two independent accumulator chains, 6 split products each) and six
+  // filler slots, one behind every MFMA pair.  A pair keeps the pipe busy for 64 cycles, i.e. ~12 issue slots
+  // that cost nothing; fillers in bigger clumps are exposed (measured: 17 % of the kernel was ds_read issue when
+  // the fillers sat in three clumps per block).  S0 / S2 / S5 carry the re-reads of w2 / w1 / w0.
+#define DDP_LYR_SB __builtin_amdgcn_sched_barrier(0);
+#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, S0, S1, S2, S3, S4, S5)                                                    \
   A0 = mma(w[0][2], X0, A0);                                                                                        \
   A1 = mma(w[1][2], X0, A1);                                                                                        \
-  RELOAD2;                                                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  S0;                                                                                                               \
+  DDP_LYR_SB                                                                                                        \
   A0 = mma(w[0][1], X1, A0);                                                                                        \
   A1 = mma(w[1][1], X1, A1);                                                                                        \
+  S1;                                                                                                               \
+  DDP_LYR_SB                                                                                                        \
   A0 = mma(w[0][1], X0, A0);                                                                                        \
   A1 = mma(w[1][1], X0, A1);                                                                                        \
-  FILL1;                                                                                                            \
-  RELOAD1;                                                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  S2;                                                                                                               \
+  DDP_LYR_SB                                                                                                        \
   A0 = mma(w[0][0], X2, A0);                                                                                        \
   A1 = mma(w[1][0], X2, A1);                                                                                        \
+  S3;                                                                                                               \
+  DDP_LYR_SB                                                                                                        \
   A0 = mma(w[0][0], X1, A0);                                                                                        \
   A1 = mma(w[1][0], X1, A1);                                                                                        \
+  S4;                                                                                                               \
+  DDP_LYR_SB                                                                                                        \
   A0 = mma(w[0][0], X0, A0);                                                                                        \
   A1 = mma(w[1][0], X0, A1);                                                                                        \
-  FILL0;                                                                                                            \
-  RELOAD0;                                                                                                          \
-  __builtin_amdgcn_sched_barrier(0);
+  S5;                                                                                                               \
+  DDP_LYR_SB
 
   // ---- kernel prologue: first two stages of the stream, bias table -> LDS
   int slot = 0;
@@ -205,21 +245,14 @@ k_layer(LayerArgs la) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const bool nb = b + 1 < 8;
-      if (s1 == 0) {
-        DDP_LYR_BLOCK(a0, a1, xa[b][0], xa[b][1], xa[b][2],
-                      if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
-                      if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
-                      if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); },
-                      dma(dslot, b, b + 1),
-                      if (b < 4) dma(dslot, 8 + b, 9 + b))
-      } else {
-        DDP_LYR_BLOCK(a0, a1, xa[8 + b][0], xa[8 + b][1], xa[8 + b][2],
-                      if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
-                      if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
-                      if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); },
-                      dma(dslot, b, b + 1),
-                      if (b < 4) dma(dslot, 8 + b, 9 + b))
-      }
+      const int kb = s1 * 8 + b;
+      DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2],
+                    if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
+                    dma(dslot, b, b + 1),
+                    if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
+                    if (b < 4) dma(dslot, 8 + b, 9 + b),
+                    {},
+                    if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); })
     }
     advance();
     wait_vm12();
@@ -288,10 +321,11 @@ k_layer(LayerArgs la) {
           const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
           DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2],
                         if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
-                        if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
-                        if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
                         dma(dslot, blk, blk + 1),
-                        if (blk < 4) dma(dslot, 8 + blk, 9 + blk))
+                        if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
+                        if (blk < 4) dma(dslot, 8 + blk, 9 + blk),
+                        {},
+                        if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); })
         }
       advance();
       wait_vm12();
@@ -371,12 +405,15 @@ k_layer(LayerArgs la) {
       tall_stage(acc1[0], acc1[1], 0);
       tall_stage(acc1[0], acc1[1], 1);
       // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2));
-      // block 0 here, block kb+1 under block kb's MFMAs
-      u32x4 hcur[3];
-      float xg[8];
+      // block 0 here, block kb+1 in the filler slots of block kb's MFMAs (two values per tile pair: GELU halves in
+      // S0..S3, split + pack of the pair in S4)
+      u32x4 hcur[3], hn[3];
+      {
+        float xg[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xg[e] = gelu_fast(acc1[0][e]);
-      split8(xg, hcur[0], hcur[1], hcur[2]);
+        for (int e = 0; e < 8; ++e) xg[e] = gelu_fast(acc1[0][e]);
+        split8(xg, hcur[0], hcur[1], hcur[2]);
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int dslot = nxt(nxt(slot));
@@ -394,20 +431,33 @@ k_layer(LayerArgs la) {
             const int blk = ks * 4 + tp;
             const bool nb = blk + 1 < 8;
             const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+            GeluHalf ga, gb;
+            float y0 = 0.f, y1 = 0.f;
+            unsigned q1 = 0, q2 = 0, q3 = 0;
             DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2],
-                          if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
-                          if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
-                          if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); },
+                          {
+                            if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); }
+                            if (kb < 3) ga = gelu_a(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
+                          },
                           {
                             dma(dslot, blk, blk + 1);
-                            if (kb < 3) xg[2 * tp] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
+                            if (kb < 3) y0 = gelu_b(ga);
+                          },
+                          {
+                            if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); }
+                            if (kb < 3) gb = gelu_a(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
                           },
                           {
                             if (blk < 4) dma(dslot, 8 + blk, 9 + blk);
-                            if (kb < 3) xg[2 * tp + 1] = gelu_fast(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
-                          })
+                            if (kb < 3) y1 = gelu_b(gb);
+                          },
+                          { if (kb < 3) { split2_pack(y0, y1, q1, q2, q3); hn[0][tp] = q1; hn[1][tp] = q2; hn[2][tp] = q3; } },
+                          if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); })
           }
-          if (kb < 3) split8(xg, hcur[0], hcur[1], hcur[2]);
+          if (kb < 3) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hcur[c] = hn[c];
+          }
         }
         advance();
         wait_vm12();
@@ -515,6 +565,7 @@ k_layer(LayerArgs la) {
     }
   }
 #undef DDP_LYR_BLOCK
+#undef DDP_LYR_SB
   wait_vm0();
 }
 
