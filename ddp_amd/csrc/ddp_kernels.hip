@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256) k_msda_gather(const float* __restrict__ v
 // 16 K16-blocks x 3 pieces x 64 lanes as fully coalesced 16-B stores.  Replaces gather + k_row_to_sb
 // (saves a 1 KiB write + 1 KiB read per token and a launch).
 constexpr int GSB_LD = 260;
-__global__ void __launch_bounds__(256) k_msda_gather_sb(const float* __restrict__ value, const float* __restrict__ samp,
+constexpr int GSB_WAVES = 8;                     // 32 tokens per block, 32 / GSB_WAVES per wave
+__global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* __restrict__ value, const float* __restrict__ samp,
                                                          unsigned short* __restrict__ out_sb, int rows, int n_tok, int h,
                                                          int w) {
   __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
@@ -220,9 +221,9 @@ __global__ void __launch_bounds__(256) k_msda_gather_sb(const float* __restrict_
   const int hd = lane >> 3;
   const int cq = (lane & 7) * 4;
   const int m_base = blockIdx.x * 32;
-#pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
-    const int jj = wave * 8 + it;
+#pragma unroll
+  for (int it = 0; it < 32 / GSB_WAVES; ++it) {
+    const int jj = wave * (32 / GSB_WAVES) + it;
     const int m = m_base + jj;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (m < rows) {
@@ -260,8 +261,8 @@ __global__ void __launch_bounds__(256) k_msda_gather_sb(const float* __restrict_
   __syncthreads();
   char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 256 * 192;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int item = r * 256 + threadIdx.x;        // (b, lane') with lane' = (h', j)
+  for (int r = 0; r < 16 / GSB_WAVES; ++r) {
+    const int item = r * 64 * GSB_WAVES + threadIdx.x;        // (b, lane') with lane' = (h', j)
     const int b = item >> 6, l2 = item & 63;
     const int j = l2 & 31, hh = l2 >> 5;
     const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
@@ -679,7 +680,7 @@ int launch_msda_gather(const float* value, const float* samp, float* out, int ro
 }
 int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                           hipStream_t st) {
-  hipLaunchKernelGGL(k_msda_gather_sb, dim3(cdiv(rows, 32)), dim3(256), 0, st, value, samp, out_sb, rows, n_tok, h, w);
+  hipLaunchKernelGGL(k_msda_gather_sb, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, value, samp, out_sb, rows, n_tok, h, w);
   return check_launch("k_msda_gather_sb");
 }
 int launch_sinusoid(const float* freq, const float* t_in, int S, float* u, hipStream_t st) {

@@ -5,6 +5,6 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
-    if 'gemm' in k or 'msda' in k or 'ffn' in k:
+    if 'gemm' in k or 'msda' in k or 'ffn' in k or 'layer' in k:
         name = k.replace('void ddp::', '').replace('ddp::(anonymous namespace)::', '')[:48]
         print(name, {c: round(sum(v) / len(v)) for c, v in sorted(d.items())})
