@@ -8,12 +8,13 @@ torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path 
 HBM.  Images shard across ranks with no data-path collective (weak scaling: B images per GPU); the
 only collective is the one-off RCCL broadcast of the frozen weights (outside the timed region).
 
-Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the fused FFN block of a decoder
-layer (b3::k_ffn: fc1 + GELU + fc2 + residual + LayerNorm + FiLM, 74 % of the loop's flops; in the
-default bf16x3 engine every fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the
-bound is the dense bf16 MFMA peak / 6), timed live with HIP events around each of its launches in a
-second pass of the same workload.  With DDP_GEMM_MODE=f32 the dominant kernel is the fp32-MFMA fc2
-GEMM + LayerNorm epilogue and the bound is the fp32 MFMA peak.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
+Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel is the persistent layer kernel
+(b3::k_layer: output_proj + LN0, FFN fc1 + GELU + fc2 + LN1 + FiLM, and the next layer's value /
+sampling projections in one launch = 89 % of the loop's flops; in the default bf16x3 engine every
+fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the bound is the dense bf16 MFMA
+peak / 6), timed live with HIP events around each of its launches in a second pass of the same
+workload.  With DDP_GEMM_MODE=f32 the dominant kernel is the fp32-MFMA fc2 GEMM + LayerNorm epilogue
+and the bound is the fp32 MFMA peak.  ``cpu_baseline``: the CPU oracle (a restatement of the reference's torch path,
 parity-pinned to golden vectors) timed on this box's host cores on a bounded sample (single
 512x1024 images of the same workload), rank 0 at N=1 only.
 """
@@ -139,12 +140,17 @@ def main():
         _lib.check(lib.ddp_profile_end(C.byref(tot), C.byref(n)))
         torch.cuda.synchronize()
         avg_ms = tot.value / max(n.value, 1)
-        if eng.gemm == 'bf16x3' and os.environ.get('DDP_FFN_FUSED', '1') != '0':
-            # fused FFN: fc1 (M,256)x(1024,256)^T + fc2 (M,1024)x(256,1024)^T, algorithmic fp32 flops
-            flops_launch = 2.0 * 2 * 256 * 1024 * M
+        if eng.gemm == 'bf16x3' and os.environ.get('DDP_LAYER_FUSED', '1') != '0':
+            # layer kernel, algorithmic fp32 flops per token: output_proj 2*256*256 + FFN 2*2*256*1024 every layer,
+            # + next layer's value_proj 2*256*256 and sampling projection 2*256*96 for all but the last layer;
+            # averaged over the L launches of a step
+            L = wl['num_layers']
+            per_tok = (L * (2 * 256 * 256 + 4 * 256 * 1024) + (L - 1) * (2 * 256 * 256 + 2 * 256 * 96)) / L
+            flops_launch = per_tok * M
             peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
-            kernel = ('b3::k_ffn<EpiResLNSB,7> (FFN fc1 + GELU + fc2 + residual + LayerNorm + FiLM; fp32 products as '
-                      '6 bf16 MFMA products, peak = 2500 TFLOP/s dense bf16 / 6)')
+            kernel = ('b3::k_layer<7> (persistent: output_proj+LN0, FFN fc1+GELU+fc2+LN1+FiLM, next value/sampling proj; '
+                      'fp32 products as 6 bf16 MFMA products, peak = 2500 TFLOP/s dense bf16 / 6; flops averaged over '
+                      'the L launches of a step)')
         elif eng.gemm == 'bf16x3':
             flops_launch = 2.0 * 256 * 1024 * M
             peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
@@ -159,6 +165,20 @@ def main():
                         frac=round(achieved / peak, 4), traffic=None,
                         launches=n.value, avg_launch_ms=round(avg_ms, 4),
                         flops_per_launch=flops_launch)
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
+        # (scripts/gpu_round.sh -> scripts/collect_profiles.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE uncalibrated)
+        try:
+            import glob
+            summ = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
+            key = 'k_layer' if 'k_layer' in kernel else ('k_gemm<8, ddp::b3::EpiResLNSB, 7>' if eng.gemm == 'bf16x3'
+                                                        else 'k_gemm_tok<8, true, ddp::EpiResLNBlk, 7>')
+            for name, e in json.load(open(summ)).items():
+                if key in name and 'hbm_read_bytes_per_launch' in e:
+                    roofline['traffic'] = int(e['hbm_read_bytes_per_launch'] + e.get('hbm_write_bytes_per_launch_uncalibrated', 0))
+                    roofline['traffic_source'] = os.path.basename(summ)
+                    break
+        except Exception:
+            pass
         # whole-loop dense-contraction rate for context
         loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes']) * float(M) * K
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)

@@ -1,4 +1,2 @@
-timeout 300 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pq -o ddp -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pq.log 2>&1
-head -12 gpurun_out/pq/ddp_kernel_stats.csv | cut -c1-150
+timeout 300 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+echo "== bench"; timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
