@@ -816,4 +816,35 @@ int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, c
   return launch_seg_update(a, static_cast<hipStream_t>(stream));
 }
 
+int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h, int w, int img_h, int img_w, int crop_h,
+                        int crop_w, int out_h, int out_w, int align_corners, int flip, unsigned char* d_seg, void* stream) {
+  DDP_TRY(check_ptr(d_scores, "scores"));
+  if (!d_seg) {
+    set_error("seg is NULL");
+    return DDP_E_NULL;
+  }
+  if (batch < 1 || num_classes < 1 || num_classes > 256 || h < 1 || w < 1 || img_h < 1 || img_w < 1 || crop_h < 1 ||
+      crop_w < 1 || crop_h > img_h || crop_w > img_w || out_h < 1 || out_w < 1 || flip < 0 || flip > 2) {
+    set_error("seg_postprocess: bad geometry (B %d K %d map %dx%d image %dx%d crop %dx%d out %dx%d flip %d)", batch,
+              num_classes, h, w, img_h, img_w, crop_h, crop_w, out_h, out_w, flip);
+    return DDP_E_BADCFG;
+  }
+  SegPostArgs a;
+  a.logits = d_scores;
+  a.B = batch;
+  a.K = num_classes;
+  a.h = h;
+  a.w = w;
+  a.H = img_h;
+  a.W = img_w;
+  a.ch = crop_h;
+  a.cw = crop_w;
+  a.oh = out_h;
+  a.ow = out_w;
+  a.align = align_corners ? 1 : 0;
+  a.flip = flip;
+  a.seg = d_seg;
+  return launch_seg_postprocess(a, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

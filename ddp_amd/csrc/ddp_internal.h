@@ -112,6 +112,16 @@ struct SegUpdateArgs {
   int rows;
 };
 int launch_seg_update(const SegUpdateArgs& a, hipStream_t st);
+struct SegPostArgs {
+  const float* logits;      // (B,K,h,w)
+  int B, K, h, w;
+  int H, W;                 // stage-1 size (padded image)
+  int ch, cw;               // crop = img_shape
+  int oh, ow;               // output = ori_shape
+  int align, flip;          // flip: 0 none, 1 horizontal, 2 vertical
+  unsigned char* seg;       // (B,oh,ow)
+};
+int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
 // out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st);

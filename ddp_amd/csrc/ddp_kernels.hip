@@ -288,6 +288,160 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Post-loop epilogue of the segmentor, fused: bilinear resize of the low-resolution class
+// scores to the (padded) image size (segmentors/ddp.py:124-128), crop to img_shape + bilinear resize to ori_shape
+// (encoder_decoder.py:236-248), softmax (:277, monotone: skipped), flip (:278-285), argmax (:296) -> uint8 map.
+// The reference materialises (1,K,H,W) fp32 twice (160 MB per 1024x2048x19 image, 315 MB at 512x1024x150); here
+// the scores are read once per tap from L2 and only the class map is written.
+// Index / weight arithmetic follows at::native::compute_source_index_and_lambda (UpSample.h): identity when
+// sizes match, src = scale*(dst+0.5)-0.5 clamped at 0 (align_corners=False) or scale*dst, scale in fp32.
+// One thread per output pixel, classes in ascending order (first maximum wins, as torch.argmax on CPU).
+// ------------------------------------------------------------------------------------------------
+struct UpIdx {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ UpIdx up_index(int dst, int in_size, int out_size, int align) {
+  UpIdx u;
+  if (in_size == out_size) {
+    u.i0 = u.i1 = dst;
+    u.l0 = 1.f;
+    u.l1 = 0.f;
+    return u;
+  }
+  float real;
+  if (align) {
+    const float scale = out_size > 1 ? float(in_size - 1) / float(out_size - 1) : 0.f;
+    real = scale * float(dst);
+  } else {
+    const float scale = float(in_size) / float(out_size);
+    real = fmaxf(__fsub_rn(__fmul_rn(scale, float(dst) + 0.5f), 0.5f), 0.f);
+  }
+  u.i0 = min(int(floorf(real)), in_size - 1);
+  u.l1 = fminf(fmaxf(real - float(u.i0), 0.f), 1.f);
+  u.i1 = u.i0 + (u.i0 < in_size - 1 ? 1 : 0);
+  u.l0 = 1.f - u.l1;
+  return u;
+}
+// (v00*wx0 + v01*wx1)*wy0 + (v10*wx0 + v11*wx1)*wy1, no contraction (the CPU kernel's nesting)
+__device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v11, const UpIdx& y, const UpIdx& x) {
+  const float top = __fadd_rn(__fmul_rn(v00, x.l0), __fmul_rn(v01, x.l1));
+  const float bot = __fadd_rn(__fmul_rn(v10, x.l0), __fmul_rn(v11, x.l1));
+  return __fadd_rn(__fmul_rn(top, y.l0), __fmul_rn(bot, y.l1));
+}
+__global__ void __launch_bounds__(256) k_seg_postprocess(SegPostArgs a) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x >= a.ow || y >= a.oh) return;
+  // flip acts on the final probabilities: out[y][x] = p[y][ow-1-x] (horizontal) / p[oh-1-y][x] (vertical)
+  const int sx = a.flip == 1 ? a.ow - 1 - x : x;
+  const int sy = a.flip == 2 ? a.oh - 1 - y : y;
+  const bool two_stage = !(a.oh == a.ch && a.ow == a.cw);
+  // stage 2 (ori <- crop of the H x W image); identity when sizes match
+  const UpIdx Y = up_index(sy, a.ch, a.oh, a.align);
+  const UpIdx X = up_index(sx, a.cw, a.ow, a.align);
+  // stage 1 (H x W <- h x w) at the (up to) 2 x 2 stage-2 taps
+  const UpIdx ya = up_index(Y.i0, a.h, a.H, a.align), yb = up_index(Y.i1, a.h, a.H, a.align);
+  const UpIdx xa = up_index(X.i0, a.w, a.W, a.align), xb = up_index(X.i1, a.w, a.W, a.align);
+  const float* plane = a.logits + size_t(b) * a.K * a.h * a.w;
+  const size_t ps = size_t(a.h) * a.w;
+  float best = -INFINITY;
+  int arg = 0;
+  for (int c = 0; c < a.K; ++c, plane += ps) {
+    const float* r0 = plane + size_t(ya.i0) * a.w;
+    const float* r1 = plane + size_t(ya.i1) * a.w;
+    float v = bilerp(r0[xa.i0], r0[xa.i1], r1[xa.i0], r1[xa.i1], ya, xa);
+    if (two_stage) {
+      const float* q0 = plane + size_t(yb.i0) * a.w;
+      const float* q1 = plane + size_t(yb.i1) * a.w;
+      const float v01 = bilerp(r0[xb.i0], r0[xb.i1], r1[xb.i0], r1[xb.i1], ya, xb);
+      const float v10 = bilerp(q0[xa.i0], q0[xa.i1], q1[xa.i0], q1[xa.i1], yb, xa);
+      const float v11 = bilerp(q0[xb.i0], q0[xb.i1], q1[xb.i0], q1[xb.i1], yb, xb);
+      v = bilerp(v, v01, v10, v11, Y, X);
+    }
+    if (v > best) {
+      best = v;
+      arg = c;
+    }
+  }
+  a.seg[(size_t(b) * a.oh + y) * a.ow + x] = (unsigned char)arg;
+}
+
+// The common case (network input = 4 x map, no crop / second resize, align_corners=False): one thread per map cell
+// produces its 4 x 4 output pixels from the cell's 3 x 3 neighbourhood - 9 loads per class instead of 64 - with the
+// interpolation done separably (4 horizontal lerps per neighbourhood row, then 16 vertical ones): the same
+// nesting, hence the same roundings, as the generic kernel and the reference's CPU kernel.
+__global__ void __launch_bounds__(256) k_seg_postprocess_x4(SegPostArgs a) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (j >= a.w || i >= a.h) return;
+  UpIdx Y[4], X[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Y[r] = up_index(4 * i + r, a.h, a.H, 0);
+    X[r] = up_index(4 * j + r, a.w, a.W, 0);
+  }
+  // rows / columns of the neighbourhood: outputs 0,1 read (r0, r1) = (i-1, i), outputs 2,3 read (i, i+1) = (r1, r2);
+  // at the top / left border the clamped source makes outputs 2,3 read (r0, r1) instead -> low tap chosen per thread
+  const int r0 = Y[0].i0, r1 = Y[0].i1, r2 = Y[3].i1;
+  const int c0 = X[0].i0, c1 = X[0].i1, c2 = X[3].i1;
+  const bool row_in = Y[2].i0 == r1, col_in = X[2].i0 == c1;
+  const float* plane = a.logits + size_t(b) * a.K * a.h * a.w;
+  const size_t ps = size_t(a.h) * a.w;
+  float best[16];
+  int arg[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    best[q] = -INFINITY;
+    arg[q] = 0;
+  }
+  for (int c = 0; c < a.K; ++c, plane += ps) {
+    float v[3][3];
+    const float* p0 = plane + size_t(r0) * a.w;
+    const float* p1 = plane + size_t(r1) * a.w;
+    const float* p2 = plane + size_t(r2) * a.w;
+    v[0][0] = p0[c0]; v[0][1] = p0[c1]; v[0][2] = p0[c2];
+    v[1][0] = p1[c0]; v[1][1] = p1[c1]; v[1][2] = p1[c2];
+    v[2][0] = p2[c0]; v[2][1] = p2[c1]; v[2][2] = p2[c2];
+    float hz[3][4];       // horizontally interpolated, per neighbourhood row
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int xq = 0; xq < 4; ++xq) {
+        const float lo = xq < 2 ? v[rr][0] : (col_in ? v[rr][1] : v[rr][0]);
+        const float hi = xq < 2 ? v[rr][1] : (col_in ? v[rr][2] : v[rr][1]);
+        hz[rr][xq] = __fadd_rn(__fmul_rn(lo, X[xq].l0), __fmul_rn(hi, X[xq].l1));
+      }
+#pragma unroll
+    for (int yq = 0; yq < 4; ++yq)
+#pragma unroll
+      for (int xq = 0; xq < 4; ++xq) {
+        const float top = yq < 2 ? hz[0][xq] : (row_in ? hz[1][xq] : hz[0][xq]);
+        const float bot = yq < 2 ? hz[1][xq] : (row_in ? hz[2][xq] : hz[1][xq]);
+        const float val = __fadd_rn(__fmul_rn(top, Y[yq].l0), __fmul_rn(bot, Y[yq].l1));
+        if (val > best[yq * 4 + xq]) {
+          best[yq * 4 + xq] = val;
+          arg[yq * 4 + xq] = c;
+        }
+      }
+  }
+#pragma unroll
+  for (int yq = 0; yq < 4; ++yq) {
+    const int oy = a.flip == 2 ? a.oh - 1 - (4 * i + yq) : 4 * i + yq;
+    unsigned packed;
+    if (a.flip == 1) {
+      packed = unsigned(arg[yq * 4 + 3]) | (unsigned(arg[yq * 4 + 2]) << 8) | (unsigned(arg[yq * 4 + 1]) << 16) | (unsigned(arg[yq * 4]) << 24);
+      *reinterpret_cast<unsigned*>(a.seg + (size_t(b) * a.oh + oy) * a.ow + (a.ow - 4 - 4 * j)) = packed;
+    } else {
+      packed = unsigned(arg[yq * 4]) | (unsigned(arg[yq * 4 + 1]) << 8) | (unsigned(arg[yq * 4 + 2]) << 16) | (unsigned(arg[yq * 4 + 3]) << 24);
+      *reinterpret_cast<unsigned*>(a.seg + (size_t(b) * a.oh + oy) * a.ow + 4 * j) = packed;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // time embedding pieces (segmentors/ddp.py:41-46,107-112; utils/transformer.py:275-278)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_sinusoid(const float* __restrict__ freq, const float* __restrict__ t_in, int S, float* __restrict__ u) {
@@ -682,6 +836,14 @@ int launch_msda_gather_sb(const float* value, const float* samp, unsigned short*
                           hipStream_t st) {
   hipLaunchKernelGGL(k_msda_gather_sb, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, value, samp, out_sb, rows, n_tok, h, w);
   return check_launch("k_msda_gather_sb");
+}
+int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st) {
+  if (a.H == 4 * a.h && a.W == 4 * a.w && a.oh == a.ch && a.ow == a.cw && a.ch == a.H && a.cw == a.W && !a.align) {
+    hipLaunchKernelGGL(k_seg_postprocess_x4, dim3(cdiv(a.w, 64), cdiv(a.h, 4), a.B), dim3(256), 0, st, a);
+    return check_launch("k_seg_postprocess_x4");
+  }
+  hipLaunchKernelGGL(k_seg_postprocess, dim3(cdiv(a.ow, 64), cdiv(a.oh, 4), a.B), dim3(256), 0, st, a);
+  return check_launch("k_seg_postprocess");
 }
 int launch_sinusoid(const float* freq, const float* t_in, int S, float* u, hipStream_t st) {
   hipLaunchKernelGGL(k_sinusoid, dim3(S), dim3(64), 0, st, freq, t_in, S, u);

@@ -204,3 +204,25 @@ class DDPEngine:
                                              self.workspace.data_ptr(), self._stream()))
         self._prepared = False      # head_forward rewrites the FiLM slot of step 0
         return out
+
+
+def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corners=False, flip=None, out=None):
+    """Fused post-loop epilogue: class map (B,out_h,out_w) uint8 from scores (B,K,h,w).
+
+    Replaces resize -> crop -> resize -> softmax -> flip -> argmax of the reference
+    (segmentors/ddp.py:124-128, encoder_decoder.py:229-296).  CUDA tensors only; no CPU path.
+    """
+    if not scores.is_cuda:
+        raise _lib.DdpError('seg_postprocess: scores must be a CUDA tensor (no CPU path)')
+    scores = scores.contiguous().float()
+    B, K, h, w = scores.shape
+    H, W = int(img_size[0]), int(img_size[1])
+    ch, cw = (H, W) if crop_size is None else (int(crop_size[0]), int(crop_size[1]))
+    oh, ow = (ch, cw) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    fl = {None: 0, False: 0, 'horizontal': 1, 'vertical': 2}[flip]
+    if out is None:
+        out = torch.empty((B, oh, ow), dtype=torch.uint8, device=scores.device)
+    lib = _lib.load()
+    _lib.check(lib.ddp_seg_postprocess(scores.data_ptr(), B, K, h, w, H, W, ch, cw, oh, ow, int(bool(align_corners)), fl,
+                                       out.data_ptr(), torch.cuda.current_stream(scores.device).cuda_stream))
+    return out

@@ -167,11 +167,37 @@ class DDP(nn.Module, _SamplerMixin):
         return F.interpolate(out, size=img.shape[2:], mode='bilinear', align_corners=self.align_corners)
 
     def whole_inference(self, img, img_meta=None, rescale=False):
-        return self.encode_decode(img, img_meta)
+        """encoder_decoder.py:229-248: crop to img_shape and resize to ori_shape when rescale."""
+        seg_logit = self.encode_decode(img, img_meta)
+        if rescale and img_meta:
+            rs = img_meta[0]['img_shape'][:2]
+            seg_logit = seg_logit[:, :, :rs[0], :rs[1]]
+            seg_logit = F.interpolate(seg_logit, size=tuple(img_meta[0]['ori_shape'][:2]), mode='bilinear',
+                                      align_corners=self.align_corners)
+        return seg_logit
 
     def simple_test(self, img, img_meta=None, rescale=True):
-        seg_logit = F.softmax(self.encode_decode(img, img_meta), dim=1)       # encoder_decoder.py:277
-        return list(seg_logit.argmax(dim=1).cpu().numpy())
+        """encoder_decoder.py:250-304 (mode='whole'), post-loop epilogue fused into one kernel:
+        the (1,K,H,W) resized scores / probabilities of the reference are never materialised."""
+        from ..engine import seg_postprocess
+        x = self.extract_feat(img)[0]
+        if self.diffusion == 'ddim':
+            out = self.ddim_sample(x, img_meta)
+        elif self.diffusion == 'ddpm':
+            out = self.ddpm_sample(x, img_meta)
+        else:
+            raise NotImplementedError
+        crop = out_size = None
+        flip = None
+        if img_meta:
+            m = img_meta[0]
+            if rescale:
+                crop = tuple(m['img_shape'][:2])
+                out_size = tuple(m['ori_shape'][:2])
+            if m.get('flip', False):
+                flip = m.get('flip_direction', 'horizontal')
+        seg = seg_postprocess(out, img.shape[2:], crop, out_size, self.align_corners, flip)
+        return list(seg.cpu().numpy().astype('int64'))
 
     def forward(self, img, img_metas=None, return_loss=False, **kwargs):
         if return_loss:

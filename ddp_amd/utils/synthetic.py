@@ -136,3 +136,9 @@ def checksum(sd):
         v = sd[k].double()
         tot += float(v.sum()) + 0.5 * float(v.abs().sum())
     return tot
+
+
+def make_scores(batch, num_classes, h, w, seed):
+    """Seeded low-resolution class scores (B,K,h,w) for the post-loop epilogue tests."""
+    g = torch.Generator().manual_seed(10_000 + seed)
+    return torch.randn((batch, num_classes, h, w), generator=g) * 3.0

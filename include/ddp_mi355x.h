@@ -163,6 +163,16 @@ int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time
 int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, const float* d_lut,
                         float* d_mask, int rows, const ddp_step* step, void* stream);
 
+/* Post-loop epilogue of the segmentor, fused: replaces
+ *   resize(out, img.shape[2:]) (segmentors/ddp.py:124-128), whole_inference's crop to img_shape + resize to
+ *   ori_shape (encoder_decoder.py:236-248), softmax (:277), flip (:278-285) and argmax (:296).
+ * d_scores (B,K,h,w) = ddp_sample's output; image (img_h,img_w) = padded network input; crop = img_shape;
+ * out = ori_shape (== crop: no second resize); flip: 0 none, 1 horizontal, 2 vertical.
+ * d_seg (B,out_h,out_w) uint8 class indices (first maximum wins).  K <= 256. */
+int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h, int w, int img_h, int img_w,
+                        int crop_h, int crop_w, int out_h, int out_w, int align_corners, int flip,
+                        unsigned char* d_seg, void* stream);
+
 /* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
  * tag: 1 xproj, 2 feat, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN,

@@ -410,3 +410,21 @@ def ddim_sample_bev(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
         mask_t = x0 * alpha_next + pred_noise * sigma_next
         outs.append(prob)
     return torch.cat(outs, dim=0).mean(dim=0, keepdim=True)
+
+
+def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corners=False, flip=None):
+    """Post-loop epilogue of the segmentor, the reference's own op sequence:
+    resize to the network input size (segmentors/ddp.py:124-128; mmseg.ops.resize == F.interpolate), crop to img_shape
+    and resize to ori_shape (encoder_decoder.py:236-248), softmax (:277), flip (:278-285), argmax (:296).
+    scores (B,K,h,w) -> int64 (B,out_h,out_w)."""
+    o = F.interpolate(scores, size=tuple(img_size), mode='bilinear', align_corners=align_corners)
+    if crop_size is not None:
+        o = o[:, :, :crop_size[0], :crop_size[1]]
+        o = F.interpolate(o, size=tuple(out_size if out_size is not None else crop_size), mode='bilinear',
+                          align_corners=align_corners)
+    o = F.softmax(o, dim=1)
+    if flip == 'horizontal':
+        o = o.flip(dims=(3,))
+    elif flip == 'vertical':
+        o = o.flip(dims=(2,))
+    return o.argmax(dim=1)

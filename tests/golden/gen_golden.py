@@ -272,17 +272,63 @@ def gen_bev():
                   x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
 
 
+POST_CASES = [
+    # network input == img_shape == ori_shape: one resize (x4), no flip
+    dict(name='post_same', num_classes=19, h=16, w=24, img=(64, 96), img_shape=(64, 96), ori_shape=(64, 96), flip=None,
+         align_corners=False, seed=0),
+    # ADE-like: padded input, crop to img_shape, shrink to ori_shape
+    dict(name='post_ade', num_classes=150, h=16, w=20, img=(64, 80), img_shape=(61, 77), ori_shape=(47, 59), flip=None,
+         align_corners=False, seed=1),
+    # odd map, enlarge to ori_shape, horizontal flip
+    dict(name='post_hflip', num_classes=19, h=13, w=17, img=(52, 68), img_shape=(52, 68), ori_shape=(75, 101),
+         flip='horizontal', align_corners=False, seed=2),
+    # vertical flip + align_corners=True
+    dict(name='post_vflip_ac', num_classes=19, h=9, w=11, img=(36, 44), img_shape=(33, 41), ori_shape=(40, 50),
+         flip='vertical', align_corners=True, seed=3),
+]
+
+
+def gen_post():
+    """Post-loop epilogue through the reference's own simple_test / inference / whole_inference /
+    encode_decode; the backbone and the sampler are replaced by seeded scores."""
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in POST_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.test_cfg.mode = 'whole'
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        model.align_corners = case['align_corners']
+        scores = synthetic.make_scores(1, case['num_classes'], case['h'], case['w'], case['seed'])
+        model.extract_feat = lambda img: [None]
+        model.ddim_sample = lambda x, img_metas: scores.clone()
+        img = torch.zeros((1, 3) + tuple(case['img']))
+        meta = [dict(img_shape=tuple(case['img_shape']) + (3,), ori_shape=tuple(case['ori_shape']) + (3,),
+                     pad_shape=tuple(case['img']) + (3,), flip=case['flip'] is not None,
+                     flip_direction=case['flip'] or 'horizontal')]
+        seg = model.simple_test(img, meta, rescale=True)[0]
+        prob = model.inference(img, meta, True)
+        top2 = prob.topk(2, dim=1).values
+        save(case['name'], dict(task='post', **case),
+             dict(seg=seg.astype('uint8'), margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=fingerprint(scores)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
-        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev}[args.task]()
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post}[args.task]()
 
 
 if __name__ == '__main__':

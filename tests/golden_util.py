@@ -16,6 +16,8 @@ def case_names(task=None):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
     if task is not None:
         names = [n for n in names if n.startswith(task)]
+    else:
+        names = [n for n in names if not n.startswith('post')]     # epilogue fixtures: load_post_case
     return names
 
 
@@ -49,3 +51,12 @@ def load_case(name):
 def max_rel(a, b):
     """max |a-b| / max |b|  (the parity metric of SURVEY.md §8d)."""
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def load_post_case(name):
+    """Post-loop epilogue fixture: -> (cfg, scores (1,K,h,w), seg uint8 (oh,ow), top-2 margin)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    scores = synthetic.make_scores(1, cfg['num_classes'], cfg['h'], cfg['w'], cfg['seed'])
+    assert np.allclose(fingerprint(scores), z['scores_fp'], rtol=1e-12)
+    return cfg, scores, torch.from_numpy(z['seg']), torch.from_numpy(z['margin'])

@@ -195,3 +195,50 @@ def test_sample_batch_matches_per_image_oracle(dev):
         assert max_rel(out[b:b + 1], ref) < REL
     # accumulated softmax means are probability vectors
     assert torch.allclose(out.sum(1), torch.ones(B, h, w), atol=1e-5)
+
+
+# ---- post-loop epilogue -----------------------------------------------------------------------
+from golden_util import load_post_case  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('post'))
+def test_post_epilogue_golden(name):
+    """fused resize/crop/resize/softmax/flip/argmax kernel vs the reference's class map: identical wherever the
+    reference's top-2 probability margin is above fp32 interpolation noise (the CPU kernel may contract to FMA)."""
+    from ddp_amd.engine import seg_postprocess
+    cfg, scores, seg, margin = load_post_case(name)
+    got = seg_postprocess(scores.cuda(), cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'], cfg['flip'])
+    torch.cuda.synchronize()
+    got = got[0].cpu()
+    diff = got != seg
+    assert diff.float().mean() < 1e-3
+    assert not (diff & (margin > 1e-5)).any()
+
+
+@pytest.mark.gpu
+def test_post_epilogue_full_size_properties():
+    """C2-size scores (8,150,128,256) -> (8,512,1024): equals the oracle on a sampled image, flip == flipped map,
+    batch entries independent."""
+    from ddp_amd.engine import seg_postprocess
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    s = synthetic.make_scores(8, 150, 128, 256, seed=77).cuda()
+    a = seg_postprocess(s, (512, 1024))
+    f = seg_postprocess(s, (512, 1024), flip='horizontal')
+    one = seg_postprocess(s[3:4], (512, 1024))
+    torch.cuda.synchronize()
+    assert torch.equal(f, a.flip(dims=(2,)))
+    assert torch.equal(one[0], a[3])
+    ref = O.seg_postprocess(s[3:4].cpu(), (512, 1024))[0]
+    assert (a[3].cpu().long() != ref).float().mean() < 1e-4
+
+
+@pytest.mark.gpu
+def test_post_epilogue_errors():
+    from ddp_amd import _lib
+    from ddp_amd.engine import seg_postprocess
+    with pytest.raises(_lib.DdpError):
+        seg_postprocess(torch.zeros(1, 19, 4, 4), (16, 16))                       # CPU tensor: no CPU path
+    with pytest.raises(_lib.DdpError):
+        seg_postprocess(torch.zeros(1, 19, 4, 4).cuda(), (16, 16), (32, 16), (16, 16))   # crop larger than the image

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ddp_oracle as O
-from golden_util import case_names, load_case, max_rel
+from golden_util import case_names, load_case, load_post_case, max_rel
 
 TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
 
@@ -91,3 +91,13 @@ def test_bev_golden(name):
                             output_scope=cfg['output_scope'])
     assert out.shape == g['out'].shape
     assert max_rel(out, g['out']) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('post'))
+def test_post_epilogue_golden(name):
+    """resize -> crop -> resize -> softmax -> flip -> argmax, fixture made by the reference's own
+    simple_test (encoder_decoder.py:229-304)."""
+    cfg, scores, seg, margin = load_post_case(name)
+    got = O.seg_postprocess(scores, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'], cfg['flip'])[0]
+    assert got.shape == seg.shape
+    assert torch.equal(got.to(torch.uint8), seg)

@@ -49,8 +49,20 @@ def test_segmentor_ddim_sample(name):
     o2 = model.encode_decode(img, None)
     assert o1.shape == (1, cfg['num_classes'], cfg['h'] * 4, cfg['w'] * 4)
     assert torch.equal(o1, o2)                       # same seed -> bit-identical, like the reference
+    torch.manual_seed(0)
     labels = model.simple_test(img, None)
     assert labels[0].shape == (cfg['h'] * 4, cfg['w'] * 4)
+    # fused epilogue == argmax of the resized scores (softmax is monotone), up to interpolation rounding at ties
+    assert (torch.from_numpy(labels[0]) != o1[0].argmax(0).cpu()).float().mean() < 1e-3
+    # rescale path: crop to img_shape, resize to ori_shape, flip (encoder_decoder.py:236-248,278-285)
+    H, W = cfg['h'] * 4, cfg['w'] * 4
+    meta = [dict(img_shape=(H - 3, W - 5, 3), ori_shape=(H + 7, W - 9, 3), flip=True, flip_direction='horizontal')]
+    torch.manual_seed(0)
+    lab2 = model.simple_test(img, meta, rescale=True)[0]
+    torch.manual_seed(0)
+    ref = torch.nn.functional.softmax(model.whole_inference(img, meta, True), dim=1).flip(dims=(3,)).argmax(1)[0].cpu()
+    assert lab2.shape == (H + 7, W - 9)
+    assert (torch.from_numpy(lab2) != ref).float().mean() < 1e-3
 
 
 def test_segmentor_ddpm_sample():
