@@ -40,6 +40,18 @@ WORKLOADS = {
                                      bit_scale=0.01, accumulation=True, num_layers=6),
     'ade_swin_t_k1_1x512x512': dict(task='seg', batch=1, h=128, w=128, timesteps=1, randsteps=1, num_classes=150,
                                     bit_scale=0.01, accumulation=True, num_layers=6),
+    # the per-GPU shards of BASELINE.json configs[2..4] (not the headline metric: no cpu_baseline / parity leg here,
+    # parity of these task variants is covered by tests/): Cityscapes Swin-L 10-step, 32x1024x2048 over 8 GPUs
+    'city_swin_l_k10_4x1024x2048': dict(task='seg', batch=4, h=256, w=512, timesteps=10, randsteps=1, num_classes=19,
+                                        bit_scale=0.01, accumulation=True, num_layers=6),
+    # KITTI depth, 20-step, 16x352x1216 on one GPU (regression head)
+    'kitti_depth_k20_16x352x1216': dict(task='depth', batch=16, h=88, w=304, timesteps=20, randsteps=1, num_classes=1,
+                                        bit_scale=0.1, accumulation=False, num_layers=6),
+    # nuScenes BEV map segmentation (fusion features), 3-step, 64x200x200 over 8 GPUs
+    'bev_fusion_k3_8x200x200': dict(task='bev', batch=8, h=128, w=128, timesteps=3, randsteps=1, num_classes=6,
+                                    bit_scale=0.01, accumulation=False, num_layers=5, feat_channels=512,
+                                    bev_input_scope=[[-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8]],
+                                    bev_output_scope=[[-50, 50, 0.5], [-50, 50, 0.5]]),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles/SIMD)
@@ -92,17 +104,22 @@ def main():
     wl = WORKLOADS[args.workload]
     B, h, w, K = wl['batch'], wl['h'], wl['w'], wl['timesteps']
     # frozen weights: generated on rank 0, replicated by ONE RCCL broadcast of the packed blob
-    sd = synthetic.make_state_dict('seg', wl['num_classes'], wl['num_layers'], 256, seed=2)
-    weights = PackedWeights(sd, 'seg', wl['num_layers'], dev)
+    task = wl['task']
+    cx = wl.get('feat_channels', 256)
+    cm = 1 if task == 'depth' else 256
+    sd = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2)
+    weights = PackedWeights(sd, task, wl['num_layers'], dev)
     if dist_on:
         if rank != 0:
             weights.flat.zero_()
         weights.broadcast(src=0)
-    eng = DDPEngine(sd, 'seg', h=h, w=w, batch=B, randsteps=wl['randsteps'], timesteps=K,
-                    num_classes=wl['num_classes'], bit_scale=wl['bit_scale'], accumulation=wl['accumulation'],
-                    device=dev, weights=weights)
+    kw = dict(h=h, w=w, batch=B, randsteps=wl['randsteps'], timesteps=K, num_classes=wl['num_classes'],
+              bit_scale=wl['bit_scale'], accumulation=wl['accumulation'], feat_channels=cx, device=dev, weights=weights)
+    if task == 'bev':
+        kw.update(bev_input_scope=wl['bev_input_scope'], bev_output_scope=wl['bev_output_scope'])
+    eng = DDPEngine(sd, task, **kw)
     # synthetic inputs, distinct per rank (independent images), resident in HBM before timing
-    x, noise = synthetic.make_inputs(B, h, w, wl['randsteps'], 256, 256, seed=1000 * rank)
+    x, noise = synthetic.make_inputs(B, h, w, wl['randsteps'], cx, cm, seed=1000 * rank)
     dx, dn = x.to(dev), noise.to(dev)
     out = torch.empty(eng.out_shape(), dtype=torch.float32, device=dev)
     eng.prepare()
@@ -129,7 +146,8 @@ def main():
 
     # ---- roofline leg: HIP events around every launch of the dominant kernel, same workload ----------
     roofline = None
-    M = B * wl['randsteps'] * h * w
+    hh, wh = eng.out_shape()[-2:]
+    M = B * wl['randsteps'] * hh * wh               # tokens on the decoder grid
     if not args.no_roofline:
         lib = _lib.load()
         _lib.check(lib.ddp_profile_begin(TAG_FC2_LN))
@@ -168,6 +186,8 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
         # (scripts/gpu_round.sh -> scripts/collect_profiles.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE uncalibrated)
         try:
+            if args.workload != 'ade_swin_t_k3_8x512x1024':
+                raise KeyError('PMC passes exist for the headline workload only')
             import glob
             summ = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
             key = 'k_layer' if 'k_layer' in kernel else ('k_gemm<8, ddp::b3::EpiResLNSB, 7>' if eng.gemm == 'bf16x3'
@@ -180,14 +200,14 @@ def main():
         except Exception:
             pass
         # whole-loop dense-contraction rate for context
-        loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes']) * float(M) * K
+        loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes'], cx) * float(M) * K
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
         roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
 
     # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ade_swin_t_k3_8x512x1024':
         from oracle import ddp_oracle as O
         cores = usable_cores()
         torch.set_num_threads(cores)
@@ -212,14 +232,17 @@ def main():
 
     if rank == 0:
         line = {
-            'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node',
+            'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node' if args.workload == 'ade_swin_t_k3_8x512x1024'
+                      else f'images/s at {K} DDIM steps ({args.workload})',
             'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (bf16x3-split MFMA products, fp32 accumulate)' if eng.gemm == 'bf16x3' else 'f32',
             'data': 'synthetic',
-            'config': {'workload': args.workload + ' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
-                                                   'per GPU; x (8,256,128,256), random-init weights)',
+            'config': {'workload': args.workload + (' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
+                                                    'per GPU; x (8,256,128,256), random-init weights)'
+                                                    if args.workload == 'ade_swin_t_k3_8x512x1024' else
+                                                    f' ({task} decoder, batch {B} per GPU, x ({B},{cx},{h},{w}), random-init weights)'),
                        'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'images_per_s_per_gpu': round(images_per_s / world, 3),
