@@ -11,6 +11,7 @@ from .segmentors.ddp import DDP  # noqa: F401
 from .decode_heads.deformable_head_with_time import DeformableHeadWithTime  # noqa: F401
 from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime  # noqa: F401
 from .bev.ddp import DDP as BEVDDP, BEVDeformableHeadWithTime  # noqa: F401
+from .necks import MultiStageMerging  # noqa: F401
 
 __all__ = ['DDP', 'DeformableHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
-           'BEVDeformableHeadWithTime', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg']
+           'BEVDeformableHeadWithTime', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg']

@@ -58,7 +58,7 @@ class DdpStep(C.Structure):
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
            'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_postprocess', 'ddp_profile_begin', 'ddp_profile_end']
+           'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_profile_begin', 'ddp_profile_end']
 
 _lib = None
 
@@ -93,6 +93,9 @@ def load():
     lib.ddp_time_embed.argtypes = [C.POINTER(DdpWeights), C.c_int, C.POINTER(C.c_float), C.c_int, _fp, _fp, _fp, _fp]
     lib.ddp_ddim_update_seg.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.POINTER(DdpStep), _fp]
     lib.ddp_seg_postprocess.argtypes = [_fp] + [C.c_int] * 12 + [_fp, _fp]
+    lib.ddp_neck_msm_workspace.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    lib.ddp_neck_msm.argtypes = [C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp,
+                                 _fp]
     lib.ddp_profile_begin.argtypes = [C.c_int]
     lib.ddp_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     for n in EXPORTS:

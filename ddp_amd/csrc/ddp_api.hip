@@ -847,4 +847,94 @@ int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h
   return launch_seg_postprocess(a, static_cast<hipStream_t>(stream));
 }
 
+namespace {
+struct MsmLayout {
+  float* tok[4];
+  unsigned short* wsplit;
+  unsigned short* a_sb;
+  float* y;
+  double* partial;
+  float* stats;
+  size_t bytes;
+};
+int msm_layout(int batch, const int* lh, const int* lw, char* base, MsmLayout* o) {
+  if (batch < 1 || !lh || !lw) {
+    set_error("neck_msm: bad arguments");
+    return DDP_E_BADCFG;
+  }
+  for (int l = 0; l < 4; ++l)
+    if (lh[l] < 1 || lw[l] < 1) {
+      set_error("neck_msm: level %d has size %dx%d", l, lh[l], lw[l]);
+      return DDP_E_BADCFG;
+    }
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  const size_t M = size_t(batch) * lh[0] * lw[0];
+  const size_t Mp = (M + 255) / 256 * 256;
+  for (int l = 0; l < 4; ++l) o->tok[l] = reinterpret_cast<float*>(take(size_t(batch) * lh[l] * lw[l] * 256 * sizeof(float)));
+  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 1024 * 2));
+  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 1024 * 3 * 2));
+  o->y = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
+  const size_t chunks = (size_t(lh[0]) * lw[0] + 255) / 256;
+  o->partial = reinterpret_cast<double*>(take(size_t(batch) * chunks * 64 * sizeof(double)));
+  o->stats = reinterpret_cast<float*>(take(size_t(batch) * 64 * sizeof(float)));
+  o->bytes = off;
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  MsmLayout o;
+  DDP_TRY(msm_layout(batch, level_h, level_w, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* level_w, int batch, const float* d_conv_w,
+                 const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out, void* d_workspace,
+                 void* stream) {
+  if (!d_levels) {
+    set_error("levels is NULL");
+    return DDP_E_NULL;
+  }
+  for (int l = 0; l < 4; ++l) DDP_TRY(check_ptr(d_levels[l], "level"));
+  DDP_TRY(check_ptr(d_conv_w, "conv weight"));
+  DDP_TRY(check_ptr(d_gn_w, "gn weight"));
+  DDP_TRY(check_ptr(d_gn_b, "gn bias"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  MsmLayout o;
+  DDP_TRY(msm_layout(batch, level_h, level_w, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = level_h[0] * level_w[0];
+  const int M = batch * N;
+  MsmArgs a;
+  for (int l = 0; l < 4; ++l) {
+    DDP_TRY(launch_nchw_to_tok(d_levels[l], o.tok[l], batch, 256, level_h[l] * level_w[l], st));
+    a.level[l] = o.tok[l];
+    a.lh[l] = level_h[l];
+    a.lw[l] = level_w[l];
+  }
+  a.h = level_h[0];
+  a.w = level_w[0];
+  a.rows = M;
+  a.align = align_corners ? 1 : 0;
+  a.out_sb = o.a_sb;
+  DDP_TRY(launch_msm_resize_sb(a, st));
+  DDP_TRY(launch_split_weights(d_conv_w, 1024, 256, 1024, o.wsplit, st));
+  SplitW w;
+  w.p = o.wsplit;
+  w.comp_stride = size_t(256) * 1024;
+  DDP_TRY(launch_b3_linear(o.a_sb, w, nullptr, nullptr, 0, 0, 0, o.y, 256, M, 256, 1024, st, TAG_GENERIC));
+  return launch_group_norm_nchw(o.y, o.partial, o.stats, d_gn_w, d_gn_b, d_out, batch, N, 1e-5f, st);
+}
+
 }  // extern "C"

@@ -122,6 +122,17 @@ struct SegPostArgs {
   unsigned char* seg;       // (B,oh,ow)
 };
 int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
+struct MsmArgs {
+  const float* level[4];    // token-major (B, N_l, 256)
+  int lh[4], lw[4];
+  int h, w;                 // output grid = level 0
+  int rows;                 // B*h*w
+  int align;
+  unsigned short* out_sb;   // SB, 1024 channels
+};
+int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st);
+int launch_group_norm_nchw(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
+                           int B, int N, float eps, hipStream_t st);
 // out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st);

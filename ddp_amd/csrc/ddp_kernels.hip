@@ -442,6 +442,144 @@ __global__ void __launch_bounds__(256) k_seg_postprocess_x4(SegPostArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MultiStageMerging neck (necks/multi_stage_merging.py:40-52): the four FPN levels are resized
+// (bilinear) to the stride-4 grid and concatenated (1024 channels), then down = ConvModule(1024, 256, 1, GN(32)).
+// The concatenation is never materialised in fp32: k_msm_resize_sb writes it directly as the SB operand of the
+// 1x1 conv GEMM; GroupNorm = deterministic two-stage statistics + normalise-and-transpose to NCHW.
+// ------------------------------------------------------------------------------------------------
+// levels are token-major (B, N_l, 256).  A block owns one 32-token SB group; per level each wave resizes 4 of its
+// tokens into a padded LDS tile (as k_msda_gather_sb), then the block emits that level's 16 K16 blocks.
+__global__ void __launch_bounds__(64 * GSB_WAVES) k_msm_resize_sb(MsmArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_base = blockIdx.x * 32;
+  const int N = a.h * a.w;
+  char* gbase = reinterpret_cast<char*>(a.out_sb) + size_t(blockIdx.x) * 1024 * 192;
+  for (int l = 0; l < 4; ++l) {
+    const int hl = a.lh[l], wl = a.lw[l];
+    const float* lv = a.level[l];
+#pragma unroll
+    for (int it = 0; it < 32 / GSB_WAVES; ++it) {
+      const int jj = wave * (32 / GSB_WAVES) + it;
+      const int m = m_base + jj;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.rows) {
+        const int b = m / N, n = m - b * N;
+        const int i = n / a.w, j = n - i * a.w;
+        const UpIdx y = up_index(i, hl, a.h, a.align), x = up_index(j, wl, a.w, a.align);
+        const float* base = lv + size_t(b) * hl * wl * 256 + lane * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + size_t(y.i0 * wl + x.i0) * 256);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + size_t(y.i0 * wl + x.i1) * 256);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + size_t(y.i1 * wl + x.i0) * 256);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + size_t(y.i1 * wl + x.i1) * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bilerp(v00[e], v01[e], v10[e], v11[e], y, x);
+      }
+      *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + lane * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16 / GSB_WAVES; ++r) {
+      const int item = r * 64 * GSB_WAVES + threadIdx.x;      // (b, lane') within this level's 256 channels
+      const int b = item >> 6, l2 = item & 63;
+      const int j = l2 & 31, hh = l2 >> 5;
+      const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
+      const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
+      unsigned short p[3][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        split3(lo4[u], p[0][u], p[1][u], p[2][u]);
+        split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
+      }
+      char* dst = gbase + size_t(l * 16 + b) * 3 * 1024 + l2 * 16;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        uint4 v;
+        v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+        v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+        v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+        v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+        *reinterpret_cast<uint4*>(dst + c * 1024) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// GroupNorm(32 groups of 8 channels) statistics over a token-major (B, N, 256) tensor, stage 1: block (chunk, b)
+// sums its 256-token chunk; thread = (token row 0..3, channel quad); partial[b][chunk][g] = {sum, sum of squares}
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ y, double* __restrict__ partial, int N,
+                                                     int chunks) {
+  __shared__ double red[4][32][2];
+  const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+  const int b = blockIdx.y, ck = blockIdx.x;
+  const int n0 = ck * 256, n1 = min(n0 + 256, N);
+  double s = 0.0, q = 0.0;
+  for (int n = n0 + row; n < n1; n += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t(b) * N + n) * 256 + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s += double(v[e]);
+      q += double(v[e]) * double(v[e]);
+    }
+  }
+  // a group = 8 channels = the lane pair (2g, 2g+1)
+  s += __shfl_xor(s, 1, 64);
+  q += __shfl_xor(q, 1, 64);
+  if ((lane & 1) == 0) {
+    red[row][lane >> 1][0] = s;
+    red[row][lane >> 1][1] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+    const double t = (red[0][g][k] + red[1][g][k]) + (red[2][g][k] + red[3][g][k]);
+    partial[((size_t(b) * chunks + ck) * 32 + g) * 2 + k] = t;
+  }
+}
+// stage 2: fixed-order sum over the chunks -> {mean, rstd} per (b, g)
+__global__ void k_gn_final(const double* __restrict__ partial, float* __restrict__ stats, int N, int chunks, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x;      // 32 threads
+  double s = 0.0, q = 0.0;
+  for (int ck = 0; ck < chunks; ++ck) {
+    s += partial[((size_t(b) * chunks + ck) * 32 + g) * 2];
+    q += partial[((size_t(b) * chunks + ck) * 32 + g) * 2 + 1];
+  }
+  const double cnt = double(N) * 8.0;
+  const double mean = s / cnt;
+  const double var = fmax(q / cnt - mean * mean, 0.0);      // biased variance, as torch.nn.GroupNorm
+  stats[(b * 32 + g) * 2] = float(mean);
+  stats[(b * 32 + g) * 2 + 1] = float(1.0 / sqrt(var + double(eps)));
+}
+// normalise + per-channel affine, token-major (B,N,256) -> NCHW (B,256,N), 64x64 tiles through LDS
+__global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__ y, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, int N) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  {
+    const int c = c0 + tx;
+    const float mean = stats[(b * 32 + (c >> 3)) * 2], rstd = stats[(b * 32 + (c >> 3)) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    for (int nn = ty; nn < 64; nn += 4) {
+      const int n = n0 + nn;
+      float v = 0.f;
+      if (n < N) v = (y[(size_t(b) * N + n) * 256 + c] - mean) * rstd * ga + be;
+      tile[nn][tx] = v;
+    }
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int n = n0 + tx;
+    if (n < N) out[(size_t(b) * 256 + c0 + cc) * N + n] = tile[tx][cc];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // time embedding pieces (segmentors/ddp.py:41-46,107-112; utils/transformer.py:275-278)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_sinusoid(const float* __restrict__ freq, const float* __restrict__ t_in, int S, float* __restrict__ u) {
@@ -844,6 +982,18 @@ int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(k_seg_postprocess, dim3(cdiv(a.ow, 64), cdiv(a.oh, 4), a.B), dim3(256), 0, st, a);
   return check_launch("k_seg_postprocess");
+}
+int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_msm_resize_sb, dim3(cdiv(a.rows, 32)), dim3(64 * GSB_WAVES), 0, st, a);
+  return check_launch("k_msm_resize_sb");
+}
+int launch_group_norm_nchw(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
+                           int B, int N, float eps, hipStream_t st) {
+  const int chunks = cdiv(N, 256);
+  hipLaunchKernelGGL(k_gn_partial, dim3(chunks, B), dim3(256), 0, st, y, partial, N, chunks);
+  hipLaunchKernelGGL(k_gn_final, dim3(B), dim3(32), 0, st, partial, stats, N, chunks, eps);
+  hipLaunchKernelGGL(k_gn_apply_nchw, dim3(cdiv(N, 64), 4, B), dim3(256), 0, st, y, stats, gamma, beta, out, N);
+  return check_launch("group_norm_nchw");
 }
 int launch_sinusoid(const float* freq, const float* t_in, int S, float* u, hipStream_t st) {
   hipLaunchKernelGGL(k_sinusoid, dim3(S), dim3(64), 0, st, freq, t_in, S, u);

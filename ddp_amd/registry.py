@@ -88,7 +88,9 @@ def register_into_mmseg():
     from .decode_heads.deformable_head_with_time import DeformableHeadWithTime
     from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime
     try:
-        from mmseg.models.builder import SEGMENTORS as MS, HEADS as MH
+        from mmseg.models.builder import SEGMENTORS as MS, HEADS as MH, NECKS as MN
+        from .necks import MultiStageMerging
+        MN.register_module(name='MultiStageMerging', force=True, module=MultiStageMerging)
         MS.register_module(name='DDP', force=True, module=DDP)
         MH.register_module(name='DeformableHeadWithTime', force=True, module=DeformableHeadWithTime)
         touched.append('mmseg')

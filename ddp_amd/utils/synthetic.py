@@ -142,3 +142,22 @@ def make_scores(batch, num_classes, h, w, seed):
     """Seeded low-resolution class scores (B,K,h,w) for the post-loop epilogue tests."""
     g = torch.Generator().manual_seed(10_000 + seed)
     return torch.randn((batch, num_classes, h, w), generator=g) * 3.0
+
+
+def make_neck_state_dict(seed):
+    """MultiStageMerging parameters with the reference's key names (necks/multi_stage_merging.py:28-37)."""
+    g = torch.Generator().manual_seed(20_000 + seed)
+    return {
+        'down.conv.weight': torch.randn((256, 1024, 1, 1), generator=g) * 0.03,
+        'down.gn.weight': 1.0 + 0.1 * torch.randn((256,), generator=g),
+        'down.gn.bias': 0.1 * torch.randn((256,), generator=g),
+    }
+
+
+def make_levels(batch, h, w, seed):
+    """Four seeded FPN-like levels (B,256,ceil(h/2^l),ceil(w/2^l)), l = 0..3."""
+    g = torch.Generator().manual_seed(30_000 + seed)
+    out = []
+    for l in range(4):
+        out.append(torch.randn((batch, 256, -(-h // (1 << l)), -(-w // (1 << l))), generator=g))
+    return out

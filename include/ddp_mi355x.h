@@ -173,6 +173,16 @@ int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h
                         int crop_h, int crop_w, int out_h, int out_w, int align_corners, int flip,
                         unsigned char* d_seg, void* stream);
 
+/* MultiStageMerging neck (necks/multi_stage_merging.py:40-52): the step that produces the frozen
+ * feature x of the sampling loop from the four FPN levels: bilinear resize of every level to level 0's grid, concat
+ * (1024 ch), down = ConvModule(1024, 256, 1, bias=False, GroupNorm(32), no activation).
+ * d_levels[l] (B,256,h_l,w_l) NCHW; d_conv_w = neck.down.conv.weight (256,1024,1,1); d_gn_w/d_gn_b = neck.down.gn.*;
+ * d_out (B,256,h_0,w_0) NCHW.  Workspace from ddp_neck_msm_workspace (caller-owned). */
+int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, size_t* bytes);
+int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* level_w, int batch,
+                 const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out,
+                 void* d_workspace, void* stream);
+
 /* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
  * tag: 1 xproj, 2 feat, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN,

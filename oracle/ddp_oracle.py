@@ -428,3 +428,13 @@ def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corne
     elif flip == 'vertical':
         o = o.flip(dims=(2,))
     return o.argmax(dim=1)
+
+
+def neck_multi_stage_merging(levels, sd, align_corners=False, prefix=''):
+    """MultiStageMerging.forward (necks/multi_stage_merging.py:40-52): resize every level to level 0's grid, concat,
+    down = ConvModule(1024,256,1, bias=False, GN(32), no act) (mmcv ConvModule order conv -> norm)."""
+    size = levels[0].shape[2:]
+    outs = [F.interpolate(t, size=tuple(size), mode='bilinear', align_corners=align_corners) for t in levels]
+    out = torch.cat(outs, dim=1)
+    out = F.conv2d(out, sd[prefix + 'down.conv.weight'])
+    return F.group_norm(out, 32, sd[prefix + 'down.gn.weight'], sd[prefix + 'down.gn.bias'], eps=1e-5)

@@ -318,17 +318,40 @@ def gen_post():
              dict(seg=seg.astype('uint8'), margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=fingerprint(scores)))
 
 
+NECK_CASES = [
+    dict(name='neck_msm_even', batch=2, h=16, w=24, align_corners=False, seed=0),
+    dict(name='neck_msm_odd', batch=1, h=13, w=19, align_corners=False, seed=1),
+    dict(name='neck_msm_ac', batch=1, h=12, w=20, align_corners=True, seed=2),
+]
+
+
+def gen_neck():
+    """MultiStageMerging from the reference class itself."""
+    import ref_shim
+    ref_shim.import_seg()
+    from mmseg.models.necks import MultiStageMerging
+    for case in NECK_CASES:
+        neck = MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None,
+                                 align_corners=case['align_corners']).eval()
+        sd = synthetic.make_neck_state_dict(case['seed'])
+        neck.load_state_dict(sd, strict=True)
+        levels = synthetic.make_levels(case['batch'], case['h'], case['w'], case['seed'])
+        out = neck(levels)[0]
+        save(case['name'], dict(task='neck', **case),
+             dict(out=out, levels_fp=np.array([fingerprint(t) for t in levels]), weights_fp=synthetic.checksum(sd)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
-        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post}[args.task]()
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck}[args.task]()
 
 
 if __name__ == '__main__':

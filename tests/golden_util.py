@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith('post')]     # epilogue fixtures: load_post_case
+        names = [n for n in names if not n.startswith(('post', 'neck'))]   # other rows: load_post_case / load_neck_case
     return names
 
 
@@ -60,3 +60,14 @@ def load_post_case(name):
     scores = synthetic.make_scores(1, cfg['num_classes'], cfg['h'], cfg['w'], cfg['seed'])
     assert np.allclose(fingerprint(scores), z['scores_fp'], rtol=1e-12)
     return cfg, scores, torch.from_numpy(z['seg']), torch.from_numpy(z['margin'])
+
+
+def load_neck_case(name):
+    """MultiStageMerging fixture: -> (cfg, levels, state_dict, out)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    sd = synthetic.make_neck_state_dict(cfg['seed'])
+    levels = synthetic.make_levels(cfg['batch'], cfg['h'], cfg['w'], cfg['seed'])
+    assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
+    assert np.allclose(np.array([fingerprint(t) for t in levels]), z['levels_fp'], rtol=1e-12)
+    return cfg, levels, sd, torch.from_numpy(z['out'])

@@ -242,3 +242,50 @@ def test_post_epilogue_errors():
         seg_postprocess(torch.zeros(1, 19, 4, 4), (16, 16))                       # CPU tensor: no CPU path
     with pytest.raises(_lib.DdpError):
         seg_postprocess(torch.zeros(1, 19, 4, 4).cuda(), (16, 16), (32, 16), (16, 16))   # crop larger than the image
+
+
+# ---- MultiStageMerging neck ----------------------------------------------------------------------
+from golden_util import load_neck_case  # noqa: E402
+
+
+def _neck(sd, align_corners):
+    import ddp_amd
+    neck = ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None,
+                                     align_corners=align_corners)
+    neck.load_state_dict(sd, strict=True)
+    return neck.cuda().eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('neck'))
+def test_neck_golden(name):
+    cfg, levels, sd, out = load_neck_case(name)
+    neck = _neck(sd, cfg['align_corners'])
+    got = neck([t.cuda() for t in levels])[0]
+    torch.cuda.synchronize()
+    assert got.shape == out.shape
+    err = max_rel(got.cpu(), out)
+    print(f'{name}: max-rel {err:.3e}')
+    assert err < REL
+
+
+@pytest.mark.gpu
+def test_neck_full_size_properties():
+    """C2-size levels (8 images, stride-4 grid 128x256): per-group statistics of the GroupNorm output, batch
+    independence, bit-reproducibility, and the oracle on one image."""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    sd = synthetic.make_neck_state_dict(5)
+    levels = [t.cuda() for t in synthetic.make_levels(8, 128, 256, 5)]
+    neck = _neck(sd, False)
+    a = neck(levels)[0]
+    b = neck(levels)[0]
+    one = neck([t[2:3] for t in levels])[0]
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                                    # deterministic two-stage GroupNorm statistics
+    assert torch.equal(one[0], a[2])                            # images are independent
+    y = (a - sd['down.gn.bias'].cuda().view(1, 256, 1, 1)) / sd['down.gn.weight'].cuda().view(1, 256, 1, 1)
+    g = y.view(8, 32, 8 * 128 * 256)
+    assert g.mean(-1).abs().max() < 1e-4 and (g.var(-1, unbiased=False) - 1).abs().max() < 1e-3
+    ref = O.neck_multi_stage_merging([t[2:3].cpu() for t in levels], sd)
+    assert max_rel(a[2:3].cpu(), ref) < REL

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ddp_oracle as O
-from golden_util import case_names, load_case, load_post_case, max_rel
+from golden_util import case_names, load_case, load_neck_case, load_post_case, max_rel
 
 TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
 
@@ -101,3 +101,12 @@ def test_post_epilogue_golden(name):
     got = O.seg_postprocess(scores, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'], cfg['flip'])[0]
     assert got.shape == seg.shape
     assert torch.equal(got.to(torch.uint8), seg)
+
+
+@pytest.mark.parametrize('name', case_names('neck'))
+def test_neck_golden(name):
+    """MultiStageMerging, fixture made by the reference class."""
+    cfg, levels, sd, out = load_neck_case(name)
+    got = O.neck_multi_stage_merging(levels, sd, cfg['align_corners'])
+    assert got.shape == out.shape
+    assert max_rel(got, out) < TOL
