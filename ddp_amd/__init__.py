@@ -7,11 +7,11 @@ state_dict keys) and passes torch device pointers to it.  There is no CPU / eage
 """
 from .registry import (MODELS, SEGMENTORS, HEADS, build_segmentor, build_depther, build_head,  # noqa: F401
                        register_into_mmseg)
-from .segmentors.ddp import DDP  # noqa: F401
+from .segmentors.ddp import DDP, SelfAlignedDDP  # noqa: F401
 from .decode_heads.deformable_head_with_time import DeformableHeadWithTime  # noqa: F401
 from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime  # noqa: F401
 from .bev.ddp import DDP as BEVDDP, BEVDeformableHeadWithTime  # noqa: F401
 from .necks import MultiStageMerging  # noqa: F401
 
-__all__ = ['DDP', 'DeformableHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
+__all__ = ['DDP', 'SelfAlignedDDP', 'DeformableHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
            'BEVDeformableHeadWithTime', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg']

@@ -84,7 +84,7 @@ def register_into_mmseg():
     """Register the MI355X classes over the reference ones in an installed mmseg / depth toolbox.
     Returns the list of registries touched (empty when none is importable)."""
     touched = []
-    from .segmentors.ddp import DDP
+    from .segmentors.ddp import DDP, SelfAlignedDDP
     from .decode_heads.deformable_head_with_time import DeformableHeadWithTime
     from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime
     try:
@@ -92,6 +92,7 @@ def register_into_mmseg():
         from .necks import MultiStageMerging
         MN.register_module(name='MultiStageMerging', force=True, module=MultiStageMerging)
         MS.register_module(name='DDP', force=True, module=DDP)
+        MS.register_module(name='SelfAlignedDDP', force=True, module=SelfAlignedDDP)
         MH.register_module(name='DeformableHeadWithTime', force=True, module=DeformableHeadWithTime)
         touched.append('mmseg')
     except Exception:

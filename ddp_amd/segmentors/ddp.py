@@ -208,3 +208,11 @@ class DDP(nn.Module, _SamplerMixin):
 
     def forward_train(self, *a, **k):
         raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
+
+
+@SEGMENTORS.register_module()
+class SelfAlignedDDP(DDP):
+    """segmentation/mmseg/models/segmentors/self_aligned_ddp.py:48-129: the self-aligned variant differs from DDP only
+    in ``forward_train`` (:131-186, out of scope); its inference surface - constructor kwargs, state_dict keys,
+    ``encode_decode`` / ``ddim_sample`` / ``ddpm_sample`` - is DDP's, so the two Cityscapes ``*_aligned`` configs
+    resolve to the same MI355X path."""

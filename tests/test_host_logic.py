@@ -165,3 +165,13 @@ def test_packed_weights_table():
     assert pw.struct.layers[2].value_proj_w is None          # unused layer slots stay NULL
     with pytest.raises(KeyError):
         PackedWeights({k: v for k, v in sd.items() if 'value_proj.weight' not in k}, 'seg', 2, 'cpu')
+
+
+def test_self_aligned_ddp_resolves_to_the_same_inference_class():
+    """configs/cityscapes/*_aligned.py use type='SelfAlignedDDP' (inference == DDP)."""
+    import ddp_amd
+    from ddp_amd.registry import SEGMENTORS
+    cls = SEGMENTORS.get('SelfAlignedDDP')
+    assert cls is ddp_amd.SelfAlignedDDP and issubclass(cls, ddp_amd.DDP)
+    for m in ('ddim_sample', 'ddpm_sample', 'encode_decode', 'simple_test'):
+        assert getattr(cls, m) is getattr(ddp_amd.DDP, m)
