@@ -68,7 +68,8 @@ class DdpError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # DDP_LIB_PATH: A/B another build of the same ABI on one GPU box (scripts/); default = the in-tree library
+    return os.environ.get('DDP_LIB_PATH') or _build.LIB_PATH
 
 
 def load():

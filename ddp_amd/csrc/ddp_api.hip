@@ -85,6 +85,8 @@ struct Layout {
   SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
       wp_f1[DDP_MAX_LAYERS];
   unsigned short *q_sb, *q1_sb, *s_sb, *h_sb, *in_sb;   // in_sb: mask / x / feat staging (row-major producers)
+  float* vpad;                                          // zero-padded value maps (R, hh+2, wh+2, 256) written by the layer kernel
+  size_t vpad_floats;
   unsigned char* wstream[DDP_MAX_LAYERS];               // layer kernel: weight stream (stage images) per layer
   float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
   size_t total;
@@ -230,6 +232,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
       const size_t rp = (rows + 255) / 256 * 256;
       return reinterpret_cast<unsigned short*>(cv.take((rp * C * 3 + 1) / 2));
     };
+    o->vpad_floats = size_t(o->R) * (o->hh + 2) * (o->wh + 2) * 256;
+    o->vpad = cv.take(o->vpad_floats);
     o->q_sb = takesb(o->M, 256);
     o->q1_sb = takesb(o->M, 256);
     o->s_sb = takesb(o->M, 256);
@@ -242,6 +246,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->in_sb = takesb(in_rows, in_c);
   } else {
     o->q_sb = o->q1_sb = o->s_sb = o->h_sb = o->in_sb = nullptr;
+    o->vpad = nullptr;
+    o->vpad_floats = 0;
   }
   o->total = cv.off * sizeof(float);
 }
@@ -352,6 +358,11 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       DDP_TRY(launch_split_weights(lw.ffn0_w, 256, DDP_FFN, 256, wr(o.wp_f0[l]), st));
       DDP_TRY(launch_split_weights(lw.ffn1_w, DDP_FFN, 256, DDP_FFN, wr(o.wp_f1[l]), st));
     }
+    // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
+    if (hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
+      set_error("hipMemsetAsync(vpad) failed");
+      return DDP_E_LAUNCH;
+    }
     // layer-kernel weight streams: [Wo: 8 wide stages][16 x (fc1 tall, tall, fc2 wide, wide)][next Wv: 8 tall][next Wcat: 4 tall]
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
@@ -398,7 +409,9 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
         DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
       }
-      DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
+      // layer 0's value map comes from the row-major GEMM; later ones are written zero-padded by the layer kernel
+      if (l == 0 || !fused) DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
+      else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
       const float* a = aff + size_t(l) * 512;
       if (fused) {
         // output_proj + LN0 + FFN + LN1 + FiLM + the next layer's value / sampling projections: one persistent kernel
@@ -415,7 +428,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         ll.be1 = a + 256;
         ll.M = M;
         ll.has_next = l + 1 < o.L;
-        ll.v_out = o.v;
+        ll.v_out = o.vpad;
         ll.samp_out = o.samp;
         ll.py = ll.has_next ? o.py[l + 1] : nullptr;
         ll.px = ll.has_next ? o.px[l + 1] : nullptr;

@@ -63,7 +63,7 @@ struct LayerLaunch {
   const float* bias_ext;
   const float *bo, *ga0, *be0, *b2, *ga1, *be1;
   int M, has_next;
-  float* v_out;
+  float* v_out;             // zero-padded value map: row of token (b,i,j) = b*(h+2)*(w+2) + (i+1)*(w+2) + (j+1)
   float* samp_out;
   const float *py, *px;
   int n_tok, w;
@@ -87,6 +87,8 @@ int launch_msda_gather(const float* value, const float* samp, float* out, int ro
                        hipStream_t st);
 int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                           hipStream_t st);
+int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
+                              hipStream_t st);
 int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);
 // y[s][o] = out_act( W[o][:] . in_act(x[s][:]) + b[o] )   act: 0 none, 1 gelu(out), 2 silu(in)
 int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,

@@ -63,7 +63,7 @@ struct LayerArgs {
   const float* be1;
   int M;
   int has_next;                  // also emit the next layer's value / sampling projections
-  float* v_out;                  // (M,256) row-major fp32
+  float* v_out;                  // fp32 rows of 256, ZERO-PADDED map: token (b,i,j) -> row b*(h+2)*(w+2) + (i+1)*(w+2) + (j+1)
   float* samp_out;               // (M,96): 64 pixel coordinates + 32 attention weights
   const float* py;               // next layer's positional tables (h,96) / (w,96), bias folded in
   const float* px;
@@ -514,13 +514,21 @@ k_layer(LayerArgs la) {
     if (la.has_next) {
       const int m = m_base + j;
       const bool valid = m < M;
+      const int mm = valid ? m : M - 1;
+      const int bimg = mm / la.n_tok;
+      const int n = mm - bimg * la.n_tok;
+      const int pi = n / la.w;
+      const int pj = n - pi * la.w;
+      const float fi = float(pi), fj = float(pj);
+      const int hmap = la.n_tok / la.w;
+      const size_t vrow = size_t(bimg) * (hmap + 2) * (la.w + 2) + size_t(pi + 1) * (la.w + 2) + (pj + 1);
       for (int vc = 0; vc < 4; ++vc) {
         f32x16 a[2];
         bias_init(a, 16 + vc);
         tall_stage(a[0], a[1], 0);
         tall_stage(a[0], a[1], 1);
         if (valid) {
-          float* dst = la.v_out + size_t(m) * 256 + vc * 64 + 4 * h;
+          float* dst = la.v_out + vrow * 256 + vc * 64 + 4 * h;
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -528,11 +536,6 @@ k_layer(LayerArgs la) {
               *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]};
         }
       }
-      const int mm = valid ? m : M - 1;
-      const int n = mm % la.n_tok;
-      const int pi = n / la.w;
-      const int pj = n - pi * la.w;
-      const float fi = float(pi), fj = float(pj);
       for (int sc2 = 0; sc2 < 2; ++sc2) {
         f32x16 a[2];
         bias_init(a, 20 + sc2);
