@@ -79,51 +79,68 @@ __device__ __forceinline__ float bf_elem(const u32x4& v, int u) {
   return __uint_as_float((u & 1) ? (w & 0xFFFF0000u) : (w << 16));
 }
 
-// gelu_fast (gemm_f32.h) in two halves of ~7 instructions so that each fits a filler slot
-struct GeluHalf { float x, t, e; };
-__device__ __forceinline__ GeluHalf gelu_a(float x) {
-  GeluHalf g;
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  g.x = x;
-  g.t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  g.e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
-  return g;
+// gelu_fast (gemm_f32.h: erf by Abramowitz-Stegun 7.1.26) + the exact 3-way bf16 split of its result as a list of
+// 18 single instructions, so that a caller can hand out "ops [LO, HI)" to the filler slot behind each MFMA: with one
+// wave per SIMD ~5 instructions hide behind an MFMA, the 6th costs ~4 cycles, the 8th ~25
+// (scripts/ubench/mfma_fill.hip).  Constants are folded so that exp2 and the final sign need no extra instruction:
+// z' = |x| sqrt(log2 e / 2);  t = 1 / (1 + p z), p z = (p / sqrt(log2 e)) z';  exp(-z^2) = exp2(-z'^2);
+// gelu = hf + |hf| erf(|x|/sqrt 2), hf = x/2.
+struct GeluState {
+  float x, a, b, c;
+  unsigned ph, pm, pl;
+};
+constexpr int GELU_OPS = 18;
+template <int OP>
+__device__ __forceinline__ void gelu_op(GeluState& g, float v) {
+  if (OP == 0) g.x = v;
+  else if (OP == 1) g.a = fabsf(g.x) * 0.84932180028801904272f;                  // z' = |x| sqrt(log2(e)/2)
+  else if (OP == 2) g.b = fmaf(0.27274550239055780f, g.a, 1.0f);                 // 1 + 0.3275911 z, z = z' / sqrt(log2 e)
+  else if (OP == 3) g.c = g.a * g.a;
+  else if (OP == 4) g.b = __builtin_amdgcn_rcpf(g.b);                            // t
+  else if (OP == 5) g.a = fmaf(1.061405429f, g.b, -1.453152027f);                // p
+  else if (OP == 6) g.c = __builtin_amdgcn_exp2f(-g.c);                          // exp(-z^2)
+  else if (OP == 7) g.a = fmaf(g.a, g.b, 1.421413741f);
+  else if (OP == 8) g.a = fmaf(g.a, g.b, -0.284496736f);
+  else if (OP == 9) g.a = fmaf(g.a, g.b, 0.254829592f);
+  else if (OP == 10) g.a = g.a * g.b;
+  else if (OP == 11) g.a = fmaf(-g.a, g.c, 1.0f);                                // erf(|x| / sqrt 2)
+  else if (OP == 12) g.b = 0.5f * g.x;
+  else if (OP == 13) g.a = fmaf(g.a, fabsf(g.b), g.b);                           // gelu(x)
+  else if (OP == 14) g.ph = __float_as_uint(g.a) & 0xFFFF0000u;
+  else if (OP == 15) g.a = g.a - __uint_as_float(g.ph);
+  else if (OP == 16) g.pm = __float_as_uint(g.a) & 0xFFFF0000u;
+  else if (OP == 17) g.pl = __float_as_uint(g.a - __uint_as_float(g.pm));
 }
-__device__ __forceinline__ float gelu_b(const GeluHalf& g) {
-  float p = fmaf(1.061405429f, g.t, -1.453152027f);
-  p = fmaf(p, g.t, 1.421413741f);
-  p = fmaf(p, g.t, -0.284496736f);
-  p = fmaf(p, g.t, 0.254829592f);
-  p *= g.t;
-  const float erf_abs = fmaf(-p, g.e, 1.0f);
-  const float h = 0.5f * g.x;
-  return fmaf(copysignf(erf_abs, g.x), h, h);
+template <int LO, int HI>
+__device__ __forceinline__ void gelu_ops(GeluState& g, float v) {
+  if constexpr (LO < HI) {
+    gelu_op<LO>(g, v);
+    gelu_ops<LO + 1, HI>(g, v);
+  }
 }
-// exact 3-way split of two fp32 values, packed as one dword per piece (element 2i in the low half)
-__device__ __forceinline__ void split2_pack(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-  const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
-  const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
-  const unsigned m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
-  const unsigned l0 = __float_as_uint(r0 - __uint_as_float(m0)), l1 = __float_as_uint(r1 - __uint_as_float(m1));
-  p1 = __builtin_amdgcn_perm(h1, h0, 0x07060302);
-  p2 = __builtin_amdgcn_perm(m1, m0, 0x07060302);
-  p3 = __builtin_amdgcn_perm(l1, l0, 0x07060302);
+// pack the pieces of an (even, odd) element pair: one dword per piece, even element in the low half
+__device__ __forceinline__ void gelu_pack(const GeluState& e, const GeluState& o, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = __builtin_amdgcn_perm(o.ph, e.ph, 0x07060302);
+  p2 = __builtin_amdgcn_perm(o.pm, e.pm, 0x07060302);
+  p3 = __builtin_amdgcn_perm(o.pl, e.pl, 0x07060302);
 }
+// ops of the even / odd value of a pair handed to filler slot k (0..11) of a block: [LO[k], LO[k+1])
+__device__ constexpr int GELU_A_LO[13] = {0, 2, 3, 5, 6, 8, 10, 12, 15, 16, 18, 18, 18};
+__device__ constexpr int GELU_B_LO[13] = {0, 1, 3, 5, 6, 8, 9, 11, 13, 14, 17, 18, 18};
 
-// one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + lane*16 + IMM) -> LDS (m0v + lane*16 + IMM)
-template <int IMM>
-__device__ __forceinline__ void stream_piece(const unsigned char* base, unsigned voff, unsigned m0v) {
-  // the operands are wave-uniform by construction; readfirstlane only tells the compiler so ("s" needs an SGPR)
-  const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
-  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b64)), hi = __builtin_amdgcn_readfirstlane(unsigned(b64 >> 32));
-  const unsigned long long bu = (static_cast<unsigned long long>(hi) << 32) | lo;
+// one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + voff + IMM) -> LDS (m0base + M0ADD + 16*lane + IMM).
+// Three instructions: everything else (stage base, ring-slot base) is computed once per stage - an MFMA hides at most
+// ~5 other instructions behind it when the SIMD runs a single wave (scripts/ubench/mfma_fill.hip), so a piece must
+// not bring its own address arithmetic.
+template <int IMM, int M0ADD>
+__device__ __forceinline__ void stream_piece(unsigned long long base, unsigned voff, unsigned m0base) {
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
+      "s_add_u32 m0, %2, %4\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %0, %1 offset:%3"
       :
-      : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(m0v)), "n"(IMM)
-      : "memory");
+      : "v"(voff), "s"(base), "s"(m0base), "n"(IMM), "n"(M0ADD)
+      : "memory", "scc");
 }
 
 template <int TAG>
@@ -139,32 +156,42 @@ k_layer(LayerArgs la) {
   const int ntiles = (M + LYR_BM - 1) / LYR_BM;
   if (int(blockIdx.x) >= ntiles) return;
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
-  const unsigned voff = unsigned(lane * 16);
+  const unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const unsigned char* const s_begin = la.stream;
-  const unsigned char* const s_end = la.stream + size_t(la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN) * LYR_STAGE_B;
-  const unsigned char* nptr = s_begin;                         // next stage image to fetch
+  const int n_stages = la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN;
+  int sidx = 0;                                                // stage image to fetch next
+  unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
+  unsigned mb = 0;                                             // ring-slot LDS base (+ this wave's share)
   auto nxt = [](int s) { return s == LYR_RING - 1 ? 0 : s + 1; };
 
-  // pieces [i0, i1) of stage image *nptr into ring slot `dslot`
-  auto dma = [&](int dslot, int i0, int i1) __attribute__((always_inline)) {
-    const unsigned char* nb = nptr + wave_off;
-    const unsigned mb = lds0 + unsigned(dslot * LYR_STAGE_B) + wave_off;
+  // once per stage: where the look-ahead comes from / goes to (kept in SGPRs), then advance the stream index
+  auto stage_begin = [&](int dslot) __attribute__((always_inline)) {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(la.stream) + size_t(sidx) * LYR_STAGE_B + wave_off;
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(p)), hi = __builtin_amdgcn_readfirstlane(unsigned(p >> 32));
+    nb = (static_cast<unsigned long long>(hi) << 32) | lo;
+    mb = __builtin_amdgcn_readfirstlane(lds0 + unsigned(dslot * LYR_STAGE_B) + wave_off);
+    sidx = sidx + 1 == n_stages ? 0 : sidx + 1;
+  };
+  // pieces [i0, i1) of that stage image
+  auto dma = [&](int i0, int i1) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       if (i < i0 || i >= i1) continue;
-      const int g = i >> 2;
-      switch (i & 3) {
-        case 0: stream_piece<0>(nb + g * 4096, voff, mb + g * 4096); break;
-        case 1: stream_piece<1024>(nb + g * 4096, voff, mb + g * 4096); break;
-        case 2: stream_piece<2048>(nb + g * 4096, voff, mb + g * 4096); break;
-        default: stream_piece<3072>(nb + g * 4096, voff, mb + g * 4096); break;
+      switch (i) {
+        case 0: stream_piece<0, 0>(nb, voff0, mb); break;
+        case 1: stream_piece<1024, 0>(nb, voff0, mb); break;
+        case 2: stream_piece<2048, 0>(nb, voff0, mb); break;
+        case 3: stream_piece<3072, 0>(nb, voff0, mb); break;
+        case 4: stream_piece<0, 4096>(nb, voff1, mb); break;
+        case 5: stream_piece<1024, 4096>(nb, voff1, mb); break;
+        case 6: stream_piece<2048, 4096>(nb, voff1, mb); break;
+        case 7: stream_piece<3072, 4096>(nb, voff1, mb); break;
+        case 8: stream_piece<0, 8192>(nb, voff2, mb); break;
+        case 9: stream_piece<1024, 8192>(nb, voff2, mb); break;
+        case 10: stream_piece<2048, 8192>(nb, voff2, mb); break;
+        default: stream_piece<3072, 8192>(nb, voff2, mb); break;
       }
     }
-  };
-  auto advance = [&]() __attribute__((always_inline)) {
-    nptr += LYR_STAGE_B;
-    nptr = nptr == s_end ? s_begin : nptr;
   };
 
   // fragment reads (per-lane base + slot base + compile-time offsets)
@@ -178,43 +205,32 @@ k_layer(LayerArgs la) {
     return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
   };
 
-  // One block = 12 MFMAs on a tile pair (two independent accumulator chains, 6 split products each) and six
-  // filler slots, one behind every MFMA pair.  A pair keeps the pipe busy for 64 cycles, i.e. ~12 issue slots
-  // that cost nothing; fillers in bigger clumps are exposed (measured: 17 % of the kernel was ds_read issue when
-  // the fillers sat in three clumps per block).  S0 / S2 / S5 carry the re-reads of w2 / w1 / w0.
+  // One block = 12 MFMAs on a tile pair (two independent accumulator chains, 6 split products each) with a filler
+  // slot behind EVERY MFMA: F(k) is whatever may issue in the shadow of MFMA k (k = 0..11), kept to <= 4-5
+  // instructions by construction (the scheduler cannot move code across the barriers).  Slots 0,1 / 4,5 / 10,11
+  // re-read w2 / w1 / w0 of the next block right after their last use.
 #define DDP_LYR_SB __builtin_amdgcn_sched_barrier(0);
-#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, S0, S1, S2, S3, S4, S5)                                                    \
-  A0 = mma(w[0][2], X0, A0);                                                                                        \
-  A1 = mma(w[1][2], X0, A1);                                                                                        \
-  S0;                                                                                                               \
-  DDP_LYR_SB                                                                                                        \
-  A0 = mma(w[0][1], X1, A0);                                                                                        \
-  A1 = mma(w[1][1], X1, A1);                                                                                        \
-  S1;                                                                                                               \
-  DDP_LYR_SB                                                                                                        \
-  A0 = mma(w[0][1], X0, A0);                                                                                        \
-  A1 = mma(w[1][1], X0, A1);                                                                                        \
-  S2;                                                                                                               \
-  DDP_LYR_SB                                                                                                        \
-  A0 = mma(w[0][0], X2, A0);                                                                                        \
-  A1 = mma(w[1][0], X2, A1);                                                                                        \
-  S3;                                                                                                               \
-  DDP_LYR_SB                                                                                                        \
-  A0 = mma(w[0][0], X1, A0);                                                                                        \
-  A1 = mma(w[1][0], X1, A1);                                                                                        \
-  S4;                                                                                                               \
-  DDP_LYR_SB                                                                                                        \
-  A0 = mma(w[0][0], X0, A0);                                                                                        \
-  A1 = mma(w[1][0], X0, A1);                                                                                        \
-  S5;                                                                                                               \
-  DDP_LYR_SB
+#define DDP_LYR_K(k) std::integral_constant<int, k>{}
+#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, F)                                                                         \
+  A0 = mma(w[0][2], X0, A0); F(DDP_LYR_K(0));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][2], X0, A1); F(DDP_LYR_K(1));  DDP_LYR_SB                                                            \
+  A0 = mma(w[0][1], X1, A0); F(DDP_LYR_K(2));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][1], X1, A1); F(DDP_LYR_K(3));  DDP_LYR_SB                                                            \
+  A0 = mma(w[0][1], X0, A0); F(DDP_LYR_K(4));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][1], X0, A1); F(DDP_LYR_K(5));  DDP_LYR_SB                                                            \
+  A0 = mma(w[0][0], X2, A0); F(DDP_LYR_K(6));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][0], X2, A1); F(DDP_LYR_K(7));  DDP_LYR_SB                                                            \
+  A0 = mma(w[0][0], X1, A0); F(DDP_LYR_K(8));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][0], X1, A1); F(DDP_LYR_K(9));  DDP_LYR_SB                                                            \
+  A0 = mma(w[0][0], X0, A0); F(DDP_LYR_K(10)); DDP_LYR_SB                                                            \
+  A1 = mma(w[1][0], X0, A1); F(DDP_LYR_K(11)); DDP_LYR_SB
 
   // ---- kernel prologue: first two stages of the stream, bias table -> LDS
   int slot = 0;
-  dma(0, 0, 12);
-  advance();
-  dma(1, 0, 12);
-  advance();
+  stage_begin(0);
+  dma(0, 12);
+  stage_begin(1);
+  dma(0, 12);
   {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + LYR_BIAS_OFF);
     for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
@@ -235,8 +251,9 @@ k_layer(LayerArgs la) {
   int ht = h;
 
   // acc (+)= W[64 rows x 256 k] . xa over two "tall" stages; the ring's look-ahead is fetched on the way
-  auto tall_stage = [&](f32x16& a0, f32x16& a1, int s1) __attribute__((always_inline)) {
-    const int dslot = nxt(nxt(slot));
+  auto tall_stage = [&](f32x16& a0, f32x16& a1, auto s1c) __attribute__((always_inline)) {
+    constexpr int s1 = decltype(s1c)::value;
+    stage_begin(nxt(nxt(slot)));
     u32x4 w[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -246,19 +263,25 @@ k_layer(LayerArgs la) {
     for (int b = 0; b < 8; ++b) {
       const bool nb = b + 1 < 8;
       const int kb = s1 * 8 + b;
-      DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2],
-                    if (nb) { w[0][2] = frag1(slot, 2, 0, b + 1); w[1][2] = frag1(slot, 2, 1, b + 1); },
-                    dma(dslot, b, b + 1),
-                    if (nb) { w[0][1] = frag1(slot, 1, 0, b + 1); w[1][1] = frag1(slot, 1, 1, b + 1); },
-                    if (b < 4) dma(dslot, 8 + b, 9 + b),
-                    {},
-                    if (nb) { w[0][0] = frag1(slot, 0, 0, b + 1); w[1][0] = frag1(slot, 0, 1, b + 1); })
+      auto fill = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 && nb) w[0][2] = frag1(slot, 2, 0, b + 1);
+        if (k == 1 && nb) w[1][2] = frag1(slot, 2, 1, b + 1);
+        if (k == 4 && nb) w[0][1] = frag1(slot, 1, 0, b + 1);
+        if (k == 5 && nb) w[1][1] = frag1(slot, 1, 1, b + 1);
+        if (k == 10 && nb) w[0][0] = frag1(slot, 0, 0, b + 1);
+        if (k == 11 && nb) w[1][0] = frag1(slot, 0, 1, b + 1);
+        if (k == 3) dma(b, b + 1);
+        if (k == 8 && b < 4) dma(8 + b, 9 + b);
+      };
+      DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], fill)
     }
-    advance();
     wait_vm12();
     __syncthreads();
     slot = nxt(slot);
   };
+  const std::integral_constant<int, 0> I0{};
+  const std::integral_constant<int, 1> I1{};
   auto bias_init = [&](f32x16 (&a)[2], int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -300,7 +323,7 @@ k_layer(LayerArgs la) {
         for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
       }
     auto p0_stage = [&](int st) __attribute__((always_inline)) {
-      const int dslot = nxt(nxt(slot));
+      stage_begin(nxt(nxt(slot)));
       const int stn = st + 1 < 8 ? st + 1 : 7;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -319,15 +342,19 @@ k_layer(LayerArgs la) {
           const int blk = ks * 4 + tp;
           const bool nb = blk + 1 < 8;
           const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
-          DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2],
-                        if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); },
-                        dma(dslot, blk, blk + 1),
-                        if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); },
-                        if (blk < 4) dma(dslot, 8 + blk, 9 + blk),
-                        {},
-                        if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); })
+          auto fill = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
+            if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
+            if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
+            if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
+            if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
+            if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
+            if (k == 3) dma(blk, blk + 1);
+            if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
+          };
+          DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2], fill)
         }
-      advance();
       wait_vm12();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -402,11 +429,11 @@ k_layer(LayerArgs la) {
     for (int hc = 0; hc < 16; ++hc) {
       f32x16 acc1[2];
       bias_init(acc1, hc);
-      tall_stage(acc1[0], acc1[1], 0);
-      tall_stage(acc1[0], acc1[1], 1);
-      // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2));
-      // block 0 here, block kb+1 in the filler slots of block kb's MFMAs (two values per tile pair: GELU halves in
-      // S0..S3, split + pack of the pair in S4)
+      tall_stage(acc1[0], acc1[1], I0);
+      tall_stage(acc1[0], acc1[1], I1);
+      // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2)).
+      // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: one element pair per
+      // block, 18 + 18 single instructions + 3 packs handed out slot by slot (GELU_A_LO / GELU_B_LO).
       u32x4 hcur[3], hn[3];
       {
         float xg[8];
@@ -416,7 +443,7 @@ k_layer(LayerArgs la) {
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int dslot = nxt(nxt(slot));
+        stage_begin(nxt(nxt(slot)));
         u32x4 w[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -431,35 +458,38 @@ k_layer(LayerArgs la) {
             const int blk = ks * 4 + tp;
             const bool nb = blk + 1 < 8;
             const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
-            GeluHalf ga, gb;
-            float y0 = 0.f, y1 = 0.f;
-            unsigned q1 = 0, q2 = 0, q3 = 0;
-            DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2],
-                          {
-                            if (nb) { w[0][2] = frag2(slot, 2, 2 * tp2, ks2); w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2); }
-                            if (kb < 3) ga = gelu_a(acc1[kn >> 1][8 * (kn & 1) + 2 * tp]);
-                          },
-                          {
-                            dma(dslot, blk, blk + 1);
-                            if (kb < 3) y0 = gelu_b(ga);
-                          },
-                          {
-                            if (nb) { w[0][1] = frag2(slot, 1, 2 * tp2, ks2); w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2); }
-                            if (kb < 3) gb = gelu_a(acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1]);
-                          },
-                          {
-                            if (blk < 4) dma(dslot, 8 + blk, 9 + blk);
-                            if (kb < 3) y1 = gelu_b(gb);
-                          },
-                          { if (kb < 3) { split2_pack(y0, y1, q1, q2, q3); hn[0][tp] = q1; hn[1][tp] = q2; hn[2][tp] = q3; } },
-                          if (nb) { w[0][0] = frag2(slot, 0, 2 * tp2, ks2); w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2); })
+            GeluState ge, go;
+            const float va = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 2 * tp] : 0.f;
+            const float vb = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1] : 0.f;
+            auto fill = [&](auto kc) __attribute__((always_inline)) {
+              constexpr int k = decltype(kc)::value;
+              if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
+              if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
+              if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
+              if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
+              if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
+              if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
+              if (k == 3) dma(blk, blk + 1);
+              if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
+              if (kb < 3) {
+                gelu_ops<GELU_A_LO[k], GELU_A_LO[k + 1]>(ge, va);
+                gelu_ops<GELU_B_LO[k], GELU_B_LO[k + 1]>(go, vb);
+                if (k == 10) {
+                  unsigned q1, q2, q3;
+                  gelu_pack(ge, go, q1, q2, q3);
+                  hn[0][tp] = q1;
+                  hn[1][tp] = q2;
+                  hn[2][tp] = q3;
+                }
+              }
+            };
+            DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2], fill)
           }
           if (kb < 3) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) hcur[c] = hn[c];
           }
         }
-        advance();
         wait_vm12();
         __syncthreads();
         slot = nxt(slot);
@@ -525,8 +555,8 @@ k_layer(LayerArgs la) {
       for (int vc = 0; vc < 4; ++vc) {
         f32x16 a[2];
         bias_init(a, 16 + vc);
-        tall_stage(a[0], a[1], 0);
-        tall_stage(a[0], a[1], 1);
+        tall_stage(a[0], a[1], I0);
+        tall_stage(a[0], a[1], I1);
         if (valid) {
           float* dst = la.v_out + vrow * 256 + vc * 64 + 4 * h;
 #pragma unroll
@@ -539,8 +569,8 @@ k_layer(LayerArgs la) {
       for (int sc2 = 0; sc2 < 2; ++sc2) {
         f32x16 a[2];
         bias_init(a, 20 + sc2);
-        tall_stage(a[0], a[1], 0);
-        tall_stage(a[0], a[1], 1);
+        tall_stage(a[0], a[1], I0);
+        tall_stage(a[0], a[1], I1);
         if (valid) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -568,6 +598,7 @@ k_layer(LayerArgs la) {
     }
   }
 #undef DDP_LYR_BLOCK
+#undef DDP_LYR_K
 #undef DDP_LYR_SB
   wait_vm0();
 }

@@ -1,1 +1,2 @@
-for i in 1 2; do for v in old new; do echo -n "$v "; DDP_LIB_PATH=$PWD/ddp_amd/lib/libddp_$v.so timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"; done; done
+timeout 400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+timeout 200 python bench.py --steps 10 --warmup 2 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['parity'])"
