@@ -950,4 +950,101 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
   return launch_group_norm_nchw(o.y, o.partial, o.stats, d_gn_w, d_gn_b, d_out, batch, N, 1e-5f, st);
 }
 
+namespace {
+struct FcnLayout {
+  float *x0, *x1, *wpack, *film, *aff, *logits;
+  unsigned short *a_sb, *wsplit, *q_sb, *wcls;
+  int ldl;
+  size_t bytes;
+};
+int fcn_layout(int maps, int h, int w, int K, char* base, FcnLayout* o) {
+  if (maps < 1 || h < 1 || w < 1 || K < 1 || K > 256) {
+    set_error("fcn_head: bad geometry (maps %d map %dx%d classes %d)", maps, h, w, K);
+    return DDP_E_BADCFG;
+  }
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  const size_t M = size_t(maps) * h * w, Mp = (M + 255) / 256 * 256;
+  o->ldl = (K + 31) / 32 * 32;
+  o->x0 = reinterpret_cast<float*>(take(Mp * 256 * 4));
+  o->x1 = reinterpret_cast<float*>(take(Mp * 256 * 4));
+  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 2304 * 6));
+  o->wpack = reinterpret_cast<float*>(take(size_t(256) * 2304 * 4));
+  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 2304 * 2));
+  o->film = reinterpret_cast<float*>(take(512 * 4));
+  o->aff = reinterpret_cast<float*>(take(512 * 4));
+  o->q_sb = reinterpret_cast<unsigned short*>(take(Mp * 256 * 6));
+  o->wcls = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 256 * 2));
+  o->logits = reinterpret_cast<float*>(take(Mp * o->ldl * 4));
+  o->bytes = off;
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  FcnLayout o;
+  DDP_TRY(fcn_layout(maps, h, w, num_classes, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
+                         int num_classes, const float* d_feat, const float* d_temb, int maps, int h, int w, float* d_out,
+                         void* d_workspace, void* stream) {
+  if (num_convs < 0 || num_convs > 8 || dilation < 1 || (num_convs > 0 && !convs)) {
+    set_error("fcn_head: num_convs %d / dilation %d out of range", num_convs, dilation);
+    return DDP_E_BADCFG;
+  }
+  DDP_TRY(check_ptr(d_cls_w, "conv_seg weight"));
+  DDP_TRY(check_ptr(d_feat, "feat"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  FcnLayout o;
+  DDP_TRY(fcn_layout(maps, h, w, num_classes, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = h * w, M = maps * N;
+  DDP_TRY(launch_nchw_to_tok(d_feat, o.x0, maps, 256, N, st));
+  float* cur = o.x0;
+  float* nxt = o.x1;
+  for (int i = 0; i < num_convs; ++i) {
+    const ddp_fcn_conv& c = convs[i];
+    DDP_TRY(check_ptr(c.conv_w, "conv weight"));
+    if (c.bn_w && (!c.bn_b || !c.bn_mean || !c.bn_var)) {
+      set_error("fcn_head: conv %d has an incomplete norm", i);
+      return DDP_E_NULL;
+    }
+    const float* film = nullptr;
+    if (d_temb && c.time_w) {      // (:216-221) SiLU -> Linear(1024, 512) -> (scale | shift)
+      DDP_TRY(launch_matvec(c.time_w, c.time_b, d_temb, o.film, DDP_TIME_DIM, 512, 1, DDP_TIME_DIM, 512, 2, 0, st));
+      film = o.film;
+    }
+    DDP_TRY(launch_fcn_fold(c.bn_w, c.bn_b, c.bn_mean, c.bn_var, c.bn_eps, c.conv_b, film, o.aff, o.aff + 256, st));
+    DDP_TRY(launch_pack_conv3x3_scaled(c.conv_w, o.aff, o.wpack, 256, 256, st));
+    DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
+    DDP_TRY(launch_im2col3x3_sb(cur, o.a_sb, maps, h, w, dilation, st));
+    SplitW wsp;
+    wsp.p = o.wsplit;
+    wsp.comp_stride = size_t(256) * 2304;
+    DDP_TRY(launch_b3_linear_act(o.a_sb, wsp, o.aff + 256, nxt, 256, M, 2304, 2, st));
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  DDP_TRY(launch_row_to_sb(cur, 256, o.q_sb, M, 256, st));
+  DDP_TRY(launch_split_weights(d_cls_w, 256, num_classes, 256, o.wcls, st));
+  SplitW wc;
+  wc.p = o.wcls;
+  wc.comp_stride = size_t(num_classes) * 256;
+  DDP_TRY(launch_b3_linear(o.q_sb, wc, d_cls_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, num_classes, 256, st, TAG_HEAD));
+  return launch_finalize_nchw(o.logits, o.ldl, d_out, maps, 1, N, num_classes, 1.0f, st);
+}
+
 }  // extern "C"

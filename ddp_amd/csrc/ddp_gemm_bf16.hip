@@ -72,6 +72,22 @@ int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* b
   return launch_b3<8, TAG_HEAD>(ga, e, st);
 }
 
+// same, with an activation on the way out (act: 0 none, 1 GELU, 2 ReLU); N = 256
+int launch_b3_linear_act(const unsigned short* A_sb, const SplitW& w, const float* bias, float* out, int ldo, int M, int K,
+                         int act, hipStream_t st) {
+  EpiRow e;
+  e.add = nullptr;
+  e.ld_add = 0;
+  e.rn = 0;
+  e.n_tok = 0;
+  e.out = out;
+  e.ldo = ldo;
+  e.n_valid = 256;
+  e.gelu = act;
+  const b3::Args ga = make_b3(A_sb, w, bias, M, 256, K);
+  return launch_b3<8, TAG_HEAD>(ga, e, st);
+}
+
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
                         hipStream_t st, int tag) {

@@ -44,6 +44,8 @@ struct SplitW {
 };
 int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                      int rn, int n_tok, float* out, int ldo, int M, int N, int K, hipStream_t st, int tag);
+int launch_b3_linear_act(const unsigned short* A_sb, const SplitW& w, const float* bias, float* out, int ldo, int M, int K,
+                         int act, hipStream_t st);
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
                         hipStream_t st, int tag);
@@ -133,6 +135,11 @@ struct MsmArgs {
   unsigned short* out_sb;   // SB, 1024 channels
 };
 int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st);
+// 3x3 convolution as a GEMM (FCNHeadWithTime): im2col straight into the SB operand, weights packed tap-major
+int launch_im2col3x3_sb(const float* x_rows, unsigned short* out_sb, int R, int h, int w, int dilation, hipStream_t st);
+int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
+int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,
+                    const float* conv_bias, const float* film, float* scale, float* shift, hipStream_t st);
 int launch_group_norm_nchw(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
                            int B, int N, float eps, hipStream_t st);
 // out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]

@@ -455,7 +455,7 @@ struct EpiRow {
   float* out;
   int ldo;
   int n_valid;        // channels >= n_valid are not stored
-  int gelu;
+  int gelu;           // 0 none, 1 GELU, 2 ReLU
 
   template <int NT>
   __device__ __forceinline__ void run(f32x16 (&acc)[NT], const LaneCtx& cx) const {
@@ -480,9 +480,12 @@ struct EpiRow {
             const int m = cx.m_base + row, ch = cbase + col;
             if (m >= cx.M || ch >= n_valid) return;
             f32x4 v = *reinterpret_cast<const f32x4*>(slot) + pre;
-            if (gelu) {
+            if (gelu == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            } else if (gelu == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             store4_guard(out + size_t(m) * ldo + ch, v, ch, n_valid);
           });

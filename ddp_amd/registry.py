@@ -94,6 +94,8 @@ def register_into_mmseg():
         MS.register_module(name='DDP', force=True, module=DDP)
         MS.register_module(name='SelfAlignedDDP', force=True, module=SelfAlignedDDP)
         MH.register_module(name='DeformableHeadWithTime', force=True, module=DeformableHeadWithTime)
+        from .decode_heads.fcn_head_with_time import FCNHeadWithTime
+        MH.register_module(name='FCNHeadWithTime', force=True, module=FCNHeadWithTime)
         touched.append('mmseg')
     except Exception:
         pass

@@ -161,3 +161,39 @@ def make_levels(batch, h, w, seed):
     for l in range(4):
         out.append(torch.randn((batch, 256, -(-h // (1 << l)), -(-w // (1 << l))), generator=g))
     return out
+
+
+def make_fcn_state_dict(num_convs, num_classes, with_norm, concat_input, seed):
+    """FCNHeadWithTime parameters / buffers with the reference's key names (decode_heads/fcn_head_with_time.py)."""
+    g = torch.Generator().manual_seed(40_000 + seed)
+    sd = {}
+
+    def bn(prefix):
+        sd[prefix + 'bn.weight'] = 1.0 + 0.2 * torch.randn((256,), generator=g)
+        sd[prefix + 'bn.bias'] = 0.1 * torch.randn((256,), generator=g)
+        sd[prefix + 'bn.running_mean'] = 0.2 * torch.randn((256,), generator=g)
+        sd[prefix + 'bn.running_var'] = 0.5 + torch.rand((256,), generator=g)
+        sd[prefix + 'bn.num_batches_tracked'] = torch.tensor(7)
+    for i in range(num_convs):
+        p = f'convs.{i}.'
+        sd[p + 'conv.weight'] = torch.randn((256, 256, 3, 3), generator=g) * 0.03
+        if with_norm:
+            bn(p)
+        else:
+            sd[p + 'conv.bias'] = 0.1 * torch.randn((256,), generator=g)
+        sd[p + 'time_mlp.1.weight'] = torch.randn((512, 1024), generator=g) * 0.02
+        sd[p + 'time_mlp.1.bias'] = 0.05 * torch.randn((512,), generator=g)
+    if concat_input:
+        sd['conv_cat.conv.weight'] = torch.randn((256, 512, 3, 3), generator=g) * 0.02
+        if with_norm:
+            bn('conv_cat.')
+        else:
+            sd['conv_cat.conv.bias'] = 0.1 * torch.randn((256,), generator=g)
+    sd['conv_seg.weight'] = torch.randn((num_classes, 256, 1, 1), generator=g) * 0.05
+    sd['conv_seg.bias'] = 0.1 * torch.randn((num_classes,), generator=g)
+    return sd
+
+
+def make_fcn_inputs(maps, h, w, seed):
+    g = torch.Generator().manual_seed(50_000 + seed)
+    return torch.randn((maps, 256, h, w), generator=g), torch.randn((1, 1024), generator=g)

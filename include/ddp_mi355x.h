@@ -183,6 +183,27 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
                  const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out,
                  void* d_workspace, void* stream);
 
+/* FCNHeadWithTime.forward (decode_heads/fcn_head_with_time.py:285-305), eval mode:
+ *   x = inputs[0]; for each ConvWithTimeModule: x = ReLU( norm(conv3x3(x)) * (scale + 1) + shift ),
+ *   (scale, shift) = Linear(SiLU(temb)).chunk(2)  (:205-225);  out = conv_seg(x)  (cls_seg, dropout is identity in eval).
+ * 256 channels in and out; the norm is an eval-mode BatchNorm (running statistics) or absent.  The reference's
+ * conv_cat is constructed but never called by _forward_feature (:285-299) and is therefore not part of the path. */
+typedef struct ddp_fcn_conv {
+  const float* conv_w;   /* convs.i.conv.weight (256,256,3,3) */
+  const float* conv_b;   /* convs.i.conv.bias (256) or NULL (bias='auto' with a norm) */
+  const float* bn_w;     /* convs.i.bn.weight / bias / running_mean / running_var (256 each), or all NULL */
+  const float* bn_b;
+  const float* bn_mean;
+  const float* bn_var;
+  float bn_eps;
+  const float* time_w;   /* convs.i.time_mlp.1.weight (512,1024) */
+  const float* time_b;   /* convs.i.time_mlp.1.bias (512) */
+} ddp_fcn_conv;
+int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* bytes);
+int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
+                         int num_classes, const float* d_feat /* (maps,256,h,w) */, const float* d_temb /* (1024) or NULL */,
+                         int maps, int h, int w, float* d_out /* (maps,num_classes,h,w) */, void* d_workspace, void* stream);
+
 /* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
  * tag: 1 xproj, 2 feat, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN,

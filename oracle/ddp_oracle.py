@@ -438,3 +438,22 @@ def neck_multi_stage_merging(levels, sd, align_corners=False, prefix=''):
     out = torch.cat(outs, dim=1)
     out = F.conv2d(out, sd[prefix + 'down.conv.weight'])
     return F.group_norm(out, 32, sd[prefix + 'down.gn.weight'], sd[prefix + 'down.gn.bias'], eps=1e-5)
+
+
+def fcn_head_forward(feat, temb, sd, num_convs, dilation=1, prefix=''):
+    """FCNHeadWithTime.forward in eval mode (decode_heads/fcn_head_with_time.py:285-305; ConvWithTimeModule.forward
+    :205-225): conv3x3 -> norm (eval BatchNorm, if any) -> x*(scale+1)+shift, (scale|shift) = Linear(SiLU(temb)) -> ReLU,
+    then cls_seg = conv_seg (dropout is the identity in eval).  conv_cat is built but never called (:285-299)."""
+    x = feat
+    for i in range(num_convs):
+        p = f'{prefix}convs.{i}.'
+        x = F.conv2d(x, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'), padding=dilation, dilation=dilation)
+        if p + 'bn.weight' in sd:
+            x = F.batch_norm(x, sd[p + 'bn.running_mean'], sd[p + 'bn.running_var'], sd[p + 'bn.weight'], sd[p + 'bn.bias'],
+                             False, 0.0, 1e-5)
+        if temb is not None:
+            te = F.linear(F.silu(temb), sd[p + 'time_mlp.1.weight'], sd[p + 'time_mlp.1.bias'])
+            scale, shift = te[:, :, None, None].chunk(2, dim=1)
+            x = x * (scale + 1) + shift
+        x = F.relu(x)
+    return F.conv2d(x, sd[prefix + 'conv_seg.weight'], sd[prefix + 'conv_seg.bias'])

@@ -341,17 +341,47 @@ def gen_neck():
              dict(out=out, levels_fp=np.array([fingerprint(t) for t in levels]), weights_fp=synthetic.checksum(sd)))
 
 
+FCN_CASES = [
+    dict(name='fcn_bn_2conv', num_convs=2, num_classes=19, with_norm=True, concat_input=True, dilation=1, maps=2, h=12, w=20,
+         seed=0, with_time=True),
+    dict(name='fcn_nonorm_1conv', num_convs=1, num_classes=150, with_norm=False, concat_input=False, dilation=1, maps=1, h=13,
+         w=17, seed=1, with_time=True),
+    dict(name='fcn_bn_dil2_notime', num_convs=2, num_classes=19, with_norm=True, concat_input=False, dilation=2, maps=1, h=10,
+         w=14, seed=2, with_time=False),
+]
+
+
+def gen_fcn():
+    """FCNHeadWithTime from the reference class itself, eval mode."""
+    import ref_shim
+    ref_shim.import_seg()
+    from mmseg.models.decode_heads import FCNHeadWithTime
+    for case in FCN_CASES:
+        head = FCNHeadWithTime(num_convs=case['num_convs'], kernel_size=3, concat_input=case['concat_input'],
+                               dilation=case['dilation'], in_channels=256, channels=256, num_classes=case['num_classes'],
+                               in_index=0, dropout_ratio=0.1, norm_cfg=dict(type='BN') if case['with_norm'] else None,
+                               align_corners=False).eval()
+        sd = synthetic.make_fcn_state_dict(case['num_convs'], case['num_classes'], case['with_norm'], case['concat_input'],
+                                           case['seed'])
+        head.load_state_dict(sd, strict=True)
+        feat, temb = synthetic.make_fcn_inputs(case['maps'], case['h'], case['w'], case['seed'])
+        times = temb.expand(case['maps'], 1024) if case['with_time'] else None
+        out = head([feat], times)
+        save(case['name'], dict(task='fcn', **case),
+             dict(out=out, feat_fp=fingerprint(feat), weights_fp=synthetic.checksum(sd)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
-        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck}[args.task]()
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn}[args.task]()
 
 
 if __name__ == '__main__':

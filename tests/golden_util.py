@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck'))]   # other rows: load_post_case / load_neck_case
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -71,3 +71,14 @@ def load_neck_case(name):
     assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
     assert np.allclose(np.array([fingerprint(t) for t in levels]), z['levels_fp'], rtol=1e-12)
     return cfg, levels, sd, torch.from_numpy(z['out'])
+
+
+def load_fcn_case(name):
+    """FCNHeadWithTime fixture: -> (cfg, feat, temb or None, state_dict, out)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    sd = synthetic.make_fcn_state_dict(cfg['num_convs'], cfg['num_classes'], cfg['with_norm'], cfg['concat_input'], cfg['seed'])
+    feat, temb = synthetic.make_fcn_inputs(cfg['maps'], cfg['h'], cfg['w'], cfg['seed'])
+    assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
+    assert np.allclose(fingerprint(feat), z['feat_fp'], rtol=1e-12)
+    return cfg, feat, (temb if cfg['with_time'] else None), sd, torch.from_numpy(z['out'])

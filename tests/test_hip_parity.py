@@ -289,3 +289,28 @@ def test_neck_full_size_properties():
     assert g.mean(-1).abs().max() < 1e-4 and (g.var(-1, unbiased=False) - 1).abs().max() < 1e-3
     ref = O.neck_multi_stage_merging([t[2:3].cpu() for t in levels], sd)
     assert max_rel(a[2:3].cpu(), ref) < REL
+
+
+# ---- FCNHeadWithTime ----------------------------------------------------------------------------
+from golden_util import load_fcn_case  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('fcn'))
+def test_fcn_head_golden(name):
+    import ddp_amd
+    cfg, feat, temb, sd, out = load_fcn_case(name)
+    head = ddp_amd.FCNHeadWithTime(num_convs=cfg['num_convs'], kernel_size=3, concat_input=cfg['concat_input'],
+                                   dilation=cfg['dilation'], in_channels=256, channels=256, num_classes=cfg['num_classes'],
+                                   in_index=0, norm_cfg=dict(type='BN') if cfg['with_norm'] else None)
+    head.load_state_dict(sd, strict=True)
+    head = head.cuda().eval()
+    times = temb.expand(cfg['maps'], 1024).cuda() if temb is not None else None
+    got = head([feat.cuda()], times)
+    torch.cuda.synchronize()
+    assert got.shape == out.shape
+    err = max_rel(got.cpu(), out)
+    print(f'{name}: max-rel {err:.3e}')
+    assert err < REL
+    with pytest.raises(Exception):
+        head([feat], None)                       # CPU tensors: no CPU path

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ddp_oracle as O
-from golden_util import case_names, load_case, load_neck_case, load_post_case, max_rel
+from golden_util import case_names, load_case, load_fcn_case, load_neck_case, load_post_case, max_rel
 
 TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
 
@@ -108,5 +108,14 @@ def test_neck_golden(name):
     """MultiStageMerging, fixture made by the reference class."""
     cfg, levels, sd, out = load_neck_case(name)
     got = O.neck_multi_stage_merging(levels, sd, cfg['align_corners'])
+    assert got.shape == out.shape
+    assert max_rel(got, out) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('fcn'))
+def test_fcn_head_golden(name):
+    """FCNHeadWithTime.forward, fixture made by the reference class (eval mode)."""
+    cfg, feat, temb, sd, out = load_fcn_case(name)
+    got = O.fcn_head_forward(feat, temb, sd, cfg['num_convs'], cfg['dilation'])
     assert got.shape == out.shape
     assert max_rel(got, out) < TOL
