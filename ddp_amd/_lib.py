@@ -56,6 +56,11 @@ class DdpStep(C.Structure):
                 ('ddpm_std', C.c_float), ('ddpm_add_noise', C.c_int32)]
 
 
+class DdpFpnLevel(C.Structure):
+    _fields_ = [('lat_w', _fp), ('lat_gn_w', _fp), ('lat_gn_b', _fp), ('out_w', _fp), ('out_gn_w', _fp), ('out_gn_b', _fp),
+                ('in_channels', C.c_int), ('h', C.c_int), ('w', C.c_int)]
+
+
 class DdpFcnConv(C.Structure):
     _fields_ = [('conv_w', _fp), ('conv_b', _fp), ('bn_w', _fp), ('bn_b', _fp), ('bn_mean', _fp), ('bn_var', _fp),
                 ('bn_eps', C.c_float), ('time_w', _fp), ('time_b', _fp)]
@@ -63,7 +68,7 @@ class DdpFcnConv(C.Structure):
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
            'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_profile_begin', 'ddp_profile_end']
+           'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end']
 
 _lib = None
 
@@ -105,6 +110,8 @@ def load():
     lib.ddp_fcn_head_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     lib.ddp_fcn_head_forward.argtypes = [C.POINTER(DdpFcnConv), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int,
                                          C.c_int, _fp, _fp, _fp]
+    lib.ddp_neck_fpn_workspace.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_neck_fpn.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]
     lib.ddp_profile_begin.argtypes = [C.c_int]
     lib.ddp_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     for n in EXPORTS:

@@ -951,6 +951,112 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
 }
 
 namespace {
+struct FpnLayout {
+  float* lat[4];            // laterals, token-major (B, N_l, 256)
+  float *tok, *y, *wpack, *stats;
+  unsigned short *a_sb, *wsplit;
+  double* partial;
+  size_t bytes;
+};
+int fpn_layout(const ddp_fpn_level* lv, int batch, char* base, FpnLayout* o) {
+  if (!lv || batch < 1) {
+    set_error("neck_fpn: bad arguments");
+    return DDP_E_BADCFG;
+  }
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  size_t max_tok = 0, max_a = 0, max_w = 0, Mp0 = 0, max_chunks = 0;
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = lv[l];
+    if (v.h < 1 || v.w < 1 || v.in_channels < 32 || v.in_channels % 32 || v.in_channels > 4096) {
+      set_error("neck_fpn: level %d: %d channels, %dx%d (channels must be a multiple of 32)", l, v.in_channels, v.h, v.w);
+      return DDP_E_BADCFG;
+    }
+    const size_t M = size_t(batch) * v.h * v.w, Mp = (M + 255) / 256 * 256;
+    o->lat[l] = reinterpret_cast<float*>(take(Mp * 256 * 4));
+    const size_t kmax = v.in_channels > 2304 ? v.in_channels : 2304;
+    if (M * v.in_channels > max_tok) max_tok = M * v.in_channels;
+    if (Mp * kmax > max_a) max_a = Mp * kmax;
+    if (kmax > max_w) max_w = kmax;
+    if (Mp > Mp0) Mp0 = Mp;
+    const size_t ch = (size_t(v.h) * v.w + 255) / 256;
+    if (ch > max_chunks) max_chunks = ch;
+  }
+  o->tok = reinterpret_cast<float*>(take(max_tok * 4));
+  o->a_sb = reinterpret_cast<unsigned short*>(take(max_a * 6));
+  o->y = reinterpret_cast<float*>(take(Mp0 * 256 * 4));
+  o->wpack = reinterpret_cast<float*>(take(size_t(256) * max_w * 4));
+  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * max_w * 2));
+  o->partial = reinterpret_cast<double*>(take(size_t(batch) * max_chunks * 64 * sizeof(double)));
+  o->stats = reinterpret_cast<float*>(take(size_t(batch) * 64 * 4));
+  o->bytes = off;
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_neck_fpn_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  FpnLayout o;
+  DDP_TRY(fpn_layout(levels, batch, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, void* d_workspace,
+                 void* stream) {
+  if (!d_in || !d_out) {
+    set_error("neck_fpn: in / out is NULL");
+    return DDP_E_NULL;
+  }
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  FpnLayout o;
+  DDP_TRY(fpn_layout(levels, batch, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // laterals (fpn.py:167-171): 1x1 conv (GEMM, K = C_l) + GroupNorm, kept token-major
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[l];
+    DDP_TRY(check_ptr(d_in[l], "level input"));
+    DDP_TRY(check_ptr(d_out[l], "level output"));
+    DDP_TRY(check_ptr(v.lat_w, "lateral weight"));
+    DDP_TRY(check_ptr(v.out_w, "fpn conv weight"));
+    const int N = v.h * v.w, M = batch * N, C = v.in_channels;
+    DDP_TRY(launch_nchw_to_tok(d_in[l], o.tok, batch, C, N, st));
+    DDP_TRY(launch_row_to_sb(o.tok, C, o.a_sb, M, C, st));
+    DDP_TRY(launch_split_weights(v.lat_w, C, 256, C, o.wsplit, st));
+    SplitW w;
+    w.p = o.wsplit;
+    w.comp_stride = size_t(256) * C;
+    DDP_TRY(launch_b3_linear_act(o.a_sb, w, nullptr, o.y, 256, M, C, 0, st));
+    DDP_TRY(launch_group_norm_rows(o.y, o.partial, o.stats, v.lat_gn_w, v.lat_gn_b, o.lat[l], batch, N, 1e-5f, st));
+  }
+  // top-down path (:173-185): nearest upsample of the coarser lateral, added in place
+  for (int l = 3; l > 0; --l)
+    DDP_TRY(launch_upsample_nearest_add(o.lat[l - 1], o.lat[l], batch, levels[l - 1].h, levels[l - 1].w, levels[l].h,
+                                        levels[l].w, st));
+  // outputs (:189-191): 3x3 conv (GEMM over im2col, K = 2304) + GroupNorm -> NCHW
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[l];
+    const int N = v.h * v.w, M = batch * N;
+    DDP_TRY(launch_pack_conv3x3_scaled(v.out_w, nullptr, o.wpack, 256, 256, st));
+    DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
+    DDP_TRY(launch_im2col3x3_sb(o.lat[l], o.a_sb, batch, v.h, v.w, 1, st));
+    SplitW w;
+    w.p = o.wsplit;
+    w.comp_stride = size_t(256) * 2304;
+    DDP_TRY(launch_b3_linear_act(o.a_sb, w, nullptr, o.y, 256, M, 2304, 0, st));
+    DDP_TRY(launch_group_norm_nchw(o.y, o.partial, o.stats, v.out_gn_w, v.out_gn_b, d_out[l], batch, N, 1e-5f, st));
+  }
+  return DDP_OK;
+}
+
+namespace {
 struct FcnLayout {
   float *x0, *x1, *wpack, *film, *aff, *logits;
   unsigned short *a_sb, *wsplit, *q_sb, *wcls;

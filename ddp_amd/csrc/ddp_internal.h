@@ -135,7 +135,10 @@ struct MsmArgs {
   unsigned short* out_sb;   // SB, 1024 channels
 };
 int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st);
-// 3x3 convolution as a GEMM (FCNHeadWithTime): im2col straight into the SB operand, weights packed tap-major
+int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
+                           int B, int N, float eps, hipStream_t st);
+int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf, int wf, int hc, int wc, hipStream_t st);
+// 3x3 convolution as a GEMM (FCNHeadWithTime, FPN): im2col straight into the SB operand, weights packed tap-major
 int launch_im2col3x3_sb(const float* x_rows, unsigned short* out_sb, int R, int h, int w, int dilation, hipStream_t st);
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,

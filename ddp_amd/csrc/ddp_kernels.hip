@@ -661,6 +661,46 @@ __global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// FPN neck pieces (necks/fpn.py:163-213): lateral 1x1 conv + GN, top-down nearest upsample + add,
+// output 3x3 conv + GN.  The convolutions are bf16x3 GEMMs (the 3x3 ones over k_im2col3x3_sb); these two kernels are
+// the token-major GroupNorm apply and the top-down step.
+// ------------------------------------------------------------------------------------------------
+// out[n][c] = (y[n][c] - mean) * rstd * gamma[c] + beta[c], token-major (B, N, 256) in and out; one wave per token
+__global__ void __launch_bounds__(256) k_gn_apply_rows(const float* __restrict__ y, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, int N, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int b = m / N;
+  const int g = lane >> 1;                       // 4 channels per lane, 8 per group
+  const float mean = stats[(b * 32 + g) * 2], rstd = stats[(b * 32 + g) * 2 + 1];
+  const f32x4 v = *reinterpret_cast<const f32x4*>(y + size_t(m) * 256 + lane * 4);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = o;
+}
+// fine[b][i][j][:] += coarse[b][min(floor(i*sy), hc-1)][min(floor(j*sx), wc-1)][:]   (F.interpolate mode='nearest',
+// at::native::nearest_neighbor_compute_source_index with scale = in/out in fp32), token-major, one wave per token
+__global__ void __launch_bounds__(256) k_upsample_nearest_add(float* __restrict__ fine, const float* __restrict__ coarse,
+                                                               int hf, int wf, int hc, int wc, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int Nf = hf * wf;
+  const int b = m / Nf, n = m - b * Nf;
+  const int i = n / wf, j = n - i * wf;
+  const float sy = float(hc) / float(hf), sx = float(wc) / float(wf);
+  const int ic = min(int(floorf(float(i) * sy)), hc - 1), jc = min(int(floorf(float(j) * sx)), wc - 1);
+  f32x4* d = reinterpret_cast<f32x4*>(fine + size_t(m) * 256 + lane * 4);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(coarse + (size_t(b) * hc * wc + ic * wc + jc) * 256 + lane * 4);
+  *d = *d + c;
+}
+
+// ------------------------------------------------------------------------------------------------
 // FCNHeadWithTime (decode_heads/fcn_head_with_time.py:205-225,285-305): each ConvWithTimeModule is
 // conv3x3 -> norm -> x*(scale+1)+shift (FiLM from the time embedding) -> ReLU.  In eval mode the norm and the FiLM are
 // one per-channel affine: the scale goes into the (re-packed) weights, the shift into the accumulator bias, ReLU into
@@ -1168,6 +1208,19 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
   hipLaunchKernelGGL(k_msda_gather_sb_pad, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, vpad, samp, out_sb, rows, n_tok, h,
                      w);
   return check_launch("k_msda_gather_sb_pad");
+}
+int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
+                           int B, int N, float eps, hipStream_t st) {
+  const int chunks = cdiv(N, 256);
+  hipLaunchKernelGGL(k_gn_partial, dim3(chunks, B), dim3(256), 0, st, y, partial, N, chunks);
+  hipLaunchKernelGGL(k_gn_final, dim3(B), dim3(32), 0, st, partial, stats, N, chunks, eps);
+  hipLaunchKernelGGL(k_gn_apply_rows, dim3(cdiv(B * N, 4)), dim3(256), 0, st, y, stats, gamma, beta, out, N, B * N);
+  return check_launch("group_norm_rows");
+}
+int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf, int wf, int hc, int wc, hipStream_t st) {
+  const int rows = B * hf * wf;
+  hipLaunchKernelGGL(k_upsample_nearest_add, dim3(cdiv(rows, 4)), dim3(256), 0, st, fine, coarse, hf, wf, hc, wc, rows);
+  return check_launch("k_upsample_nearest_add");
 }
 int launch_im2col3x3_sb(const float* x_rows, unsigned short* out_sb, int R, int h, int w, int dilation, hipStream_t st) {
   const int rows = R * h * w;

@@ -1,1 +1,2 @@
+from .fpn import FPN  # noqa: F401
 from .multi_stage_merging import MultiStageMerging  # noqa: F401

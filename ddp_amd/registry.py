@@ -89,8 +89,9 @@ def register_into_mmseg():
     from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime
     try:
         from mmseg.models.builder import SEGMENTORS as MS, HEADS as MH, NECKS as MN
-        from .necks import MultiStageMerging
+        from .necks import FPN, MultiStageMerging
         MN.register_module(name='MultiStageMerging', force=True, module=MultiStageMerging)
+        MN.register_module(name='FPN', force=True, module=FPN)
         MS.register_module(name='DDP', force=True, module=DDP)
         MS.register_module(name='SelfAlignedDDP', force=True, module=SelfAlignedDDP)
         MH.register_module(name='DeformableHeadWithTime', force=True, module=DeformableHeadWithTime)

@@ -197,3 +197,23 @@ def make_fcn_state_dict(num_convs, num_classes, with_norm, concat_input, seed):
 def make_fcn_inputs(maps, h, w, seed):
     g = torch.Generator().manual_seed(50_000 + seed)
     return torch.randn((maps, 256, h, w), generator=g), torch.randn((1, 1024), generator=g)
+
+
+def make_fpn_state_dict(in_channels, seed):
+    """FPN parameters with the reference's key names (necks/fpn.py:119-134)."""
+    g = torch.Generator().manual_seed(60_000 + seed)
+    sd = {}
+    for l, c in enumerate(in_channels):
+        sd[f'lateral_convs.{l}.conv.weight'] = torch.randn((256, c, 1, 1), generator=g) * (1.0 / c ** 0.5)
+        sd[f'lateral_convs.{l}.gn.weight'] = 1.0 + 0.1 * torch.randn((256,), generator=g)
+        sd[f'lateral_convs.{l}.gn.bias'] = 0.1 * torch.randn((256,), generator=g)
+        sd[f'fpn_convs.{l}.conv.weight'] = torch.randn((256, 256, 3, 3), generator=g) * 0.03
+        sd[f'fpn_convs.{l}.gn.weight'] = 1.0 + 0.1 * torch.randn((256,), generator=g)
+        sd[f'fpn_convs.{l}.gn.bias'] = 0.1 * torch.randn((256,), generator=g)
+    return sd
+
+
+def make_backbone_levels(batch, in_channels, h, w, seed):
+    """Four seeded backbone-like levels (B,C_l,ceil(h/2^l),ceil(w/2^l))."""
+    g = torch.Generator().manual_seed(70_000 + seed)
+    return [torch.randn((batch, c, -(-h // (1 << l)), -(-w // (1 << l))), generator=g) for l, c in enumerate(in_channels)]

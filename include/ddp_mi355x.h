@@ -183,6 +183,22 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
                  const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out,
                  void* d_workspace, void* stream);
 
+/* FPN neck (necks/fpn.py:163-213) as the DDP configs build it: 4 levels, lateral ConvModule(C_l,256,1,
+ * bias=False, GN(32), no act), top-down nearest upsample + add, output ConvModule(256,256,3,padding=1,bias=False,GN(32),
+ * no act); num_outs = 4 (no extra levels).  d_in[l] (B,C_l,h_l,w_l) NCHW, C_l % 32 == 0; d_out[l] (B,256,h_l,w_l) NCHW. */
+typedef struct ddp_fpn_level {
+  const float* lat_w;      /* lateral_convs.l.conv.weight (256,C_l,1,1) */
+  const float* lat_gn_w;   /* lateral_convs.l.gn.weight / bias (256) */
+  const float* lat_gn_b;
+  const float* out_w;      /* fpn_convs.l.conv.weight (256,256,3,3) */
+  const float* out_gn_w;   /* fpn_convs.l.gn.weight / bias (256) */
+  const float* out_gn_b;
+  int in_channels, h, w;
+} ddp_fpn_level;
+int ddp_neck_fpn_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes);
+int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, void* d_workspace,
+                 void* stream);
+
 /* FCNHeadWithTime.forward (decode_heads/fcn_head_with_time.py:285-305), eval mode:
  *   x = inputs[0]; for each ConvWithTimeModule: x = ReLU( norm(conv3x3(x)) * (scale + 1) + shift ),
  *   (scale, shift) = Linear(SiLU(temb)).chunk(2)  (:205-225);  out = conv_seg(x)  (cls_seg, dropout is identity in eval).

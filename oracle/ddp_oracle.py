@@ -457,3 +457,20 @@ def fcn_head_forward(feat, temb, sd, num_convs, dilation=1, prefix=''):
             x = x * (scale + 1) + shift
         x = F.relu(x)
     return F.conv2d(x, sd[prefix + 'conv_seg.weight'], sd[prefix + 'conv_seg.bias'])
+
+
+def neck_fpn(inputs, sd, prefix=''):
+    """FPN.forward of the DDP configs (necks/fpn.py:163-191): laterals = GN(conv1x1), top-down nearest upsample + add,
+    outs = GN(conv3x3(lateral)); 4 levels, no activation, no extra levels."""
+    lat = []
+    for l, x in enumerate(inputs):
+        p = f'{prefix}lateral_convs.{l}.'
+        lat.append(F.group_norm(F.conv2d(x, sd[p + 'conv.weight']), 32, sd[p + 'gn.weight'], sd[p + 'gn.bias'], eps=1e-5))
+    for l in range(len(lat) - 1, 0, -1):
+        lat[l - 1] = lat[l - 1] + F.interpolate(lat[l], size=lat[l - 1].shape[2:], mode='nearest')
+    outs = []
+    for l, x in enumerate(lat):
+        p = f'{prefix}fpn_convs.{l}.'
+        outs.append(F.group_norm(F.conv2d(x, sd[p + 'conv.weight'], padding=1), 32, sd[p + 'gn.weight'], sd[p + 'gn.bias'],
+                                 eps=1e-5))
+    return tuple(outs)

@@ -371,17 +371,40 @@ def gen_fcn():
              dict(out=out, feat_fp=fingerprint(feat), weights_fp=synthetic.checksum(sd)))
 
 
+FPN_CASES = [
+    dict(name='fpn_swin_t', in_channels=[96, 192, 384, 768], batch=2, h=16, w=24, seed=0),      # configs/ade/ddp_swin_t...:41-46
+    dict(name='fpn_odd', in_channels=[128, 256, 512, 1024], batch=1, h=13, w=19, seed=1),       # odd sizes: 13,7,4,2 rows
+]
+
+
+def gen_fpn():
+    """FPN from the reference class itself."""
+    import ref_shim
+    ref_shim.import_seg()
+    from mmseg.models.necks import FPN
+    for case in FPN_CASES:
+        neck = FPN(in_channels=case['in_channels'], out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32),
+                   num_outs=4).eval()
+        sd = synthetic.make_fpn_state_dict(case['in_channels'], case['seed'])
+        neck.load_state_dict(sd, strict=True)
+        levels = synthetic.make_backbone_levels(case['batch'], case['in_channels'], case['h'], case['w'], case['seed'])
+        outs = neck(levels)
+        arrays = {f'out{l}': o for l, o in enumerate(outs)}
+        arrays.update(levels_fp=np.array([fingerprint(t) for t in levels]), weights_fp=synthetic.checksum(sd))
+        save(case['name'], dict(task='fpn', **case), arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
-        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn}[args.task]()
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn}[args.task]()
 
 
 if __name__ == '__main__':

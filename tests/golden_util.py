@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -82,3 +82,14 @@ def load_fcn_case(name):
     assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
     assert np.allclose(fingerprint(feat), z['feat_fp'], rtol=1e-12)
     return cfg, feat, (temb if cfg['with_time'] else None), sd, torch.from_numpy(z['out'])
+
+
+def load_fpn_case(name):
+    """FPN fixture: -> (cfg, backbone levels, state_dict, [4 outputs])."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    sd = synthetic.make_fpn_state_dict(cfg['in_channels'], cfg['seed'])
+    levels = synthetic.make_backbone_levels(cfg['batch'], cfg['in_channels'], cfg['h'], cfg['w'], cfg['seed'])
+    assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
+    assert np.allclose(np.array([fingerprint(t) for t in levels]), z['levels_fp'], rtol=1e-12)
+    return cfg, levels, sd, [torch.from_numpy(z[f'out{l}']) for l in range(4)]

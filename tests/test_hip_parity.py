@@ -314,3 +314,45 @@ def test_fcn_head_golden(name):
     assert err < REL
     with pytest.raises(Exception):
         head([feat], None)                       # CPU tensors: no CPU path
+
+
+# ---- FPN neck -----------------------------------------------------------------------------------
+from golden_util import load_fpn_case  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('fpn'))
+def test_fpn_golden(name):
+    import ddp_amd
+    cfg, levels, sd, outs = load_fpn_case(name)
+    neck = ddp_amd.FPN(in_channels=cfg['in_channels'], out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32),
+                       num_outs=4)
+    neck.load_state_dict(sd, strict=True)
+    neck = neck.cuda().eval()
+    got = neck([t.cuda() for t in levels])
+    torch.cuda.synchronize()
+    for l, (g, o) in enumerate(zip(got, outs)):
+        assert g.shape == o.shape
+        err = max_rel(g.cpu(), o)
+        print(f'{name} level {l}: max-rel {err:.3e}')
+        assert err < REL
+
+
+@pytest.mark.gpu
+def test_fpn_then_merging_chain_matches_oracle():
+    """the two necks chained as in the DDP configs (configs/ade/ddp_swin_t...:39-54) == the oracle chain"""
+    import ddp_amd
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    inc = [96, 192, 384, 768]
+    sdf, sdm = synthetic.make_fpn_state_dict(inc, 3), synthetic.make_neck_state_dict(3)
+    fpn = ddp_amd.FPN(in_channels=inc, out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32), num_outs=4)
+    msm = ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None)
+    fpn.load_state_dict(sdf)
+    msm.load_state_dict(sdm)
+    chain = torch.nn.Sequential(fpn, msm).cuda().eval()
+    levels = synthetic.make_backbone_levels(2, inc, 32, 48, 3)
+    got = chain([t.cuda() for t in levels])[0]
+    torch.cuda.synchronize()
+    ref = O.neck_multi_stage_merging(list(O.neck_fpn(levels, sdf)), sdm)
+    assert max_rel(got.cpu(), ref) < REL

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ddp_oracle as O
-from golden_util import case_names, load_case, load_fcn_case, load_neck_case, load_post_case, max_rel
+from golden_util import case_names, load_case, load_fcn_case, load_fpn_case, load_neck_case, load_post_case, max_rel
 
 TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
 
@@ -119,3 +119,13 @@ def test_fcn_head_golden(name):
     got = O.fcn_head_forward(feat, temb, sd, cfg['num_convs'], cfg['dilation'])
     assert got.shape == out.shape
     assert max_rel(got, out) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('fpn'))
+def test_fpn_golden(name):
+    """FPN, fixture made by the reference class."""
+    cfg, levels, sd, outs = load_fpn_case(name)
+    got = O.neck_fpn(levels, sd)
+    for g, o in zip(got, outs):
+        assert g.shape == o.shape
+        assert max_rel(g, o) < TOL
