@@ -87,6 +87,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2, help='images timed on the CPU oracle (bounded sample)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--next-rows', action='store_true',
+                    help='also time the rows either side of the loop on the same batch (SURVEY.md §8 f1/f2): FPN + '
+                         'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -204,6 +207,34 @@ def main():
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
         roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
 
+    # ---- rows either side of the loop (optional, rank 0): the neck that produces x, the epilogue that consumes out --
+    next_rows = None
+    if args.next_rows and rank == 0 and task == 'seg':
+        import ddp_amd
+        from ddp_amd.engine import seg_postprocess
+        inc = [96, 192, 384, 768]                                       # Swin-T stages (configs/ade/ddp_swin_t...:41)
+        fpn = ddp_amd.FPN(in_channels=inc, out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32), num_outs=4)
+        msm = ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None)
+        fpn.load_state_dict(synthetic.make_fpn_state_dict(inc, 1))
+        msm.load_state_dict(synthetic.make_neck_state_dict(1))
+        fpn, msm = fpn.to(dev).eval(), msm.to(dev).eval()
+        lv = [t.to(dev) for t in synthetic.make_backbone_levels(B, inc, h, w, 1)]
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps * 1e3, r
+        t_fpn, f_out = timed(lambda: fpn(lv))
+        t_msm, _ = timed(lambda: msm(list(f_out)))
+        t_post, _ = timed(lambda: seg_postprocess(out, (4 * hh, 4 * wh)))
+        next_rows = {'neck_fpn_ms': round(t_fpn, 3), 'neck_multi_stage_merging_ms': round(t_msm, 3),
+                     'post_epilogue_ms': round(t_post, 3), 'loop_ms': round(ms_per_step, 3),
+                     'note': 'same batch, synthetic backbone levels (Swin-T channels); backbone itself stays PyTorch-ROCm'}
+
     # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
     cpu = None
     parity = None
@@ -246,7 +277,7 @@ def main():
                        'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'images_per_s_per_gpu': round(images_per_s / world, 3),
-            'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
+            'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

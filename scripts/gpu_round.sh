@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.txt
 cat $OUT/pytest_gpu.txt
-python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 10 --warmup 2 --next-rows > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json; tail -3 $OUT/bench.err
 REPO=$PWD
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
