@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libddp_mi355x.so')
 SOURCES = ['ddp_api.hip', 'ddp_gemm.hip', 'ddp_gemm_bf16.hip', 'ddp_kernels.hip']
 HEADERS = ['ddp_internal.h', 'gemm_f32.h', 'gemm_bf16x3.h', 'layer_bf16x3.h', os.path.join('..', '..', 'include', 'ddp_mi355x.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 
 
 def _hipcc():

@@ -870,7 +870,7 @@ struct MsmLayout {
   float* stats;
   size_t bytes;
 };
-int msm_layout(int batch, const int* lh, const int* lw, char* base, MsmLayout* o) {
+static int msm_layout(int batch, const int* lh, const int* lw, char* base, MsmLayout* o) {
   if (batch < 1 || !lh || !lw) {
     set_error("neck_msm: bad arguments");
     return DDP_E_BADCFG;
@@ -958,7 +958,7 @@ struct FpnLayout {
   double* partial;
   size_t bytes;
 };
-int fpn_layout(const ddp_fpn_level* lv, int batch, char* base, FpnLayout* o) {
+static int fpn_layout(const ddp_fpn_level* lv, int batch, char* base, FpnLayout* o) {
   if (!lv || batch < 1) {
     set_error("neck_fpn: bad arguments");
     return DDP_E_BADCFG;
@@ -1063,7 +1063,7 @@ struct FcnLayout {
   int ldl;
   size_t bytes;
 };
-int fcn_layout(int maps, int h, int w, int K, char* base, FcnLayout* o) {
+static int fcn_layout(int maps, int h, int w, int K, char* base, FcnLayout* o) {
   if (maps < 1 || h < 1 || w < 1 || K < 1 || K > 256) {
     set_error("fcn_head: bad geometry (maps %d map %dx%d classes %d)", maps, h, w, K);
     return DDP_E_BADCFG;

@@ -6,7 +6,7 @@
 
 namespace ddp {
 
-unsigned long long* g_gemm_dbg = nullptr;   // probe: per-block cycle stamps (ddp_debug_set_stamps)
+unsigned long long* const g_gemm_dbg = nullptr;   // per-block cycle stamps of k_gemm_tok (DDP_STAMP): off
 
 namespace {
 
@@ -132,4 +132,3 @@ int launch_linear_samp(const float* A_blk, const float* Wcat, const float* py, c
 
 }  // namespace ddp
 
-extern "C" void ddp_debug_set_stamps(void* buf) { ddp::g_gemm_dbg = static_cast<unsigned long long*>(buf); }

@@ -33,6 +33,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define DDP_ABI_VERSION 2
 #define DDP_MAX_LAYERS 12
@@ -227,6 +231,9 @@ int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation,
 int ddp_profile_begin(int tag);
 int ddp_profile_end(float* total_ms, int* launches);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,14 @@ def test_exports_match_header():
     for n in names:
         assert hasattr(lib, n), n
     assert set(_lib.EXPORTS) == names
+    # ... and nothing else is (the library is built with -fvisibility=hidden)
+    import shutil
+    import subprocess
+    nm = shutil.which('nm')
+    if nm:
+        out = subprocess.run([nm, '-D', '--defined-only', _lib.lib_path()], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ' T ' in ln}
+        assert exported == names, exported ^ names
 
 
 def test_cfg_validation_without_gpu():
