@@ -1,6 +1,6 @@
 // How many independent filler instructions hide behind one v_mfma_f32_32x32x16_bf16 when a SIMD runs ONE wave?
 // Kernel: 256 threads (one wave per SIMD), loop of [MFMA on accumulator A or B alternately ; K fillers], fillers =
-// fp32 VALU (v_fma), ds_read_b128 (+ a counted wait), or SALU.  Prints cycles per MFMA for K = 0..10.
+// fp32 VALU (v_fma; independent or in 1 / 2 / 3 dependent chains), v_exp_f32, ds_read_b128 (+ a counted wait), or SALU.  Prints cycles per MFMA for K = 0..10.
 // hipcc --offload-arch=gfx950 -O2 mfma_fill.hip -o mfma_fill
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -31,8 +31,16 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, float* sink
         } else if (KIND == 1) {
           if (q % 2 == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(lr[(q / 2) % 4]) : "v"((threadIdx.x & 63) * 16 + (q / 2) * 1024));
           else asm volatile("s_waitcnt lgkmcnt(3)");
-        } else {
+        } else if (KIND == 2) {
           asm volatile("s_nop 0");
+        } else if (KIND == 3) {          // ONE dependent chain: every filler needs the previous one's result
+          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[0]));
+        } else if (KIND == 4) {          // two interleaved dependent chains (distance 2)
+          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[q & 1]));
+        } else if (KIND == 5) {          // three interleaved dependent chains (distance 3)
+          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[q % 3]));
+        } else {                         // transcendental (quarter rate): v_exp_f32, independent
+          asm volatile("v_exp_f32 %0, %0" : "+v"(f[q % 12]));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -70,5 +78,9 @@ int main() {
   sweep<0>("v_fma_f32", d_out, d_sink);
   sweep<1>("ds_read_b128 / s_waitcnt", d_out, d_sink);
   sweep<2>("s_nop", d_out, d_sink);
+  sweep<3>("v_fma_f32, ONE dependent chain", d_out, d_sink);
+  sweep<4>("v_fma_f32, two dependent chains interleaved", d_out, d_sink);
+  sweep<5>("v_fma_f32, three dependent chains interleaved", d_out, d_sink);
+  sweep<6>("v_exp_f32 (independent)", d_out, d_sink);
   return 0;
 }
