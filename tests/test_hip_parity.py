@@ -356,3 +356,21 @@ def test_fpn_then_merging_chain_matches_oracle():
     torch.cuda.synchronize()
     ref = O.neck_multi_stage_merging(list(O.neck_fpn(levels, sdf)), sdm)
     assert max_rel(got.cpu(), ref) < REL
+
+
+# ---- edge geometry: single-token maps, one layer (no "next layer" projections), the class-count limits ---------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,L,K,r', [(1, 1, 1, 2, 1), (2, 3, 2, 256, 2), (5, 4, 1, 19, 1), (3, 50, 3, 150, 1)])
+def test_sample_edge_geometry_vs_oracle(dev, h, w, L, K, r):
+    """maps smaller than one 32-token group / one 128-token tile, a single decoder layer, 2 and 256 classes"""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    sd = synthetic.make_state_dict('seg', K, L, 256, seed=11)
+    x, noise = synthetic.make_inputs(2, h, w, r, 256, 256, seed=12)
+    cfg = dict(task='seg', h=h, w=w, randsteps=r, timesteps=2, bit_scale=0.01, num_classes=K, accumulation=True,
+               noise_schedule='cosine', diffusion='ddim')
+    eng = _engine(cfg, sd, dev, batch=2)
+    out = eng.sample(x.to(dev), noise.to(dev)).cpu()
+    for b in range(2):
+        ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=2, randsteps=r, bit_scale=0.01, accumulation=True)
+        assert max_rel(out[b:b + 1], ref) < REL
