@@ -374,3 +374,19 @@ def test_sample_edge_geometry_vs_oracle(dev, h, w, L, K, r):
     for b in range(2):
         ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=2, randsteps=r, bit_scale=0.01, accumulation=True)
         assert max_rel(out[b:b + 1], ref) < REL
+
+
+@pytest.mark.gpu
+def test_sample_more_tiles_than_cus_ragged(dev):
+    """33 150 tokens = 259 layer-kernel tiles on 256 CUs: blocks that walk two tiles, and a ragged last tile"""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    h, w, L, K = 130, 255, 2, 19
+    sd = synthetic.make_state_dict('seg', K, L, 256, seed=21)
+    x, noise = synthetic.make_inputs(1, h, w, 1, 256, 256, seed=22)
+    cfg = dict(task='seg', h=h, w=w, randsteps=1, timesteps=1, bit_scale=0.01, num_classes=K, accumulation=False,
+               noise_schedule='cosine', diffusion='ddim')
+    eng = _engine(cfg, sd, dev, batch=1)
+    out = eng.sample(x.to(dev), noise.to(dev)).cpu()
+    ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=1, randsteps=1, bit_scale=0.01, accumulation=False)
+    assert max_rel(out, ref) < REL
