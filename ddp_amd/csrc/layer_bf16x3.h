@@ -86,8 +86,7 @@ __device__ __forceinline__ float bf_elem(const u32x4& v, int u) {
 // z' = |x| sqrt(log2 e / 2);  t = 1 / (1 + p z), p z = (p / sqrt(log2 e)) z';  exp(-z^2) = exp2(-z'^2);
 // gelu = hf + |hf| erf(|x|/sqrt 2), hf = x/2.
 struct GeluState {
-  float x, a, b, c;
-  unsigned ph, pm, pl;
+  float x, a, b, c;      // after op 17 the three bf16 pieces live in (b, c, a): gelu_ph / gelu_pm / gelu_pl
 };
 constexpr int GELU_OPS = 18;
 template <int OP>
@@ -106,27 +105,48 @@ __device__ __forceinline__ void gelu_op(GeluState& g, float v) {
   else if (OP == 11) g.a = fmaf(-g.a, g.c, 1.0f);                                // erf(|x| / sqrt 2)
   else if (OP == 12) g.b = 0.5f * g.x;
   else if (OP == 13) g.a = fmaf(g.a, fabsf(g.b), g.b);                           // gelu(x)
-  else if (OP == 14) g.ph = __float_as_uint(g.a) & 0xFFFF0000u;
-  else if (OP == 15) g.a = g.a - __uint_as_float(g.ph);
-  else if (OP == 16) g.pm = __float_as_uint(g.a) & 0xFFFF0000u;
-  else if (OP == 17) g.pl = __float_as_uint(g.a - __uint_as_float(g.pm));
+  else if (OP == 14) g.b = __uint_as_float(__float_as_uint(g.a) & 0xFFFF0000u);  // piece 1
+  else if (OP == 15) g.a = g.a - g.b;
+  else if (OP == 16) g.c = __uint_as_float(__float_as_uint(g.a) & 0xFFFF0000u);  // piece 2
+  else if (OP == 17) g.a = g.a - g.c;                                            // piece 3 (its high half)
 }
-template <int LO, int HI>
-__device__ __forceinline__ void gelu_ops(GeluState& g, float v) {
-  if constexpr (LO < HI) {
-    gelu_op<LO>(g, v);
-    gelu_ops<LO + 1, HI>(g, v);
-  }
+__device__ __forceinline__ unsigned gelu_ph(const GeluState& g) { return __float_as_uint(g.b); }
+__device__ __forceinline__ unsigned gelu_pm(const GeluState& g) { return __float_as_uint(g.c); }
+__device__ __forceinline__ unsigned gelu_pl(const GeluState& g) { return __float_as_uint(g.a); }
+template <int OP>
+__device__ __forceinline__ void gelu_maybe(GeluState& g, float v) {
+  if constexpr (OP >= 0) gelu_op<OP>(g, v);
 }
-// pack the pieces of an (even, odd) element pair: one dword per piece, even element in the low half
-__device__ __forceinline__ void gelu_pack(const GeluState& e, const GeluState& o, unsigned& p1, unsigned& p2, unsigned& p3) {
-  p1 = __builtin_amdgcn_perm(o.ph, e.ph, 0x07060302);
-  p2 = __builtin_amdgcn_perm(o.pm, e.pm, 0x07060302);
-  p3 = __builtin_amdgcn_perm(o.pl, e.pl, 0x07060302);
-}
-// ops of the even / odd value of a pair handed to filler slot k (0..11) of a block: [LO[k], LO[k+1])
-__device__ constexpr int GELU_A_LO[13] = {0, 2, 3, 5, 6, 8, 10, 12, 15, 16, 18, 18, 18};
-__device__ constexpr int GELU_B_LO[13] = {0, 1, 3, 5, 6, 8, 9, 11, 13, 14, 17, 18, 18};
+// Schedule of FOUR values over the 24 filler slots of two consecutive MFMA blocks: GELU_SCHED[slot][value] = the
+// instruction of that value issued in that slot (-1: none).  At most one instruction per value per slot (four
+// independent dependency chains: a dependent VALU instruction behind an MFMA costs ~8 cycles, an independent one 4),
+// at most 5 issue units per slot counting the slot's ds_read (1), its DMA piece (2) and v_rcp / v_exp double;
+// slots 21..23 carry the six packs.  Built by a greedy list scheduler.
+__device__ constexpr int GELU_SCHED[24][4] = {
+    { 0,  0,  0,  0},
+    { 1,  1,  1,  1},
+    { 2,  2,  2,  2},
+    {-1,  3,  3,  3},
+    { 3,  4, -1, -1},
+    { 4, -1, -1,  4},
+    { 5,  5,  4,  5},
+    {-1,  6,  5,  6},
+    { 6,  7, -1, -1},
+    { 7,  8,  6,  7},
+    { 8,  9,  7,  8},
+    { 9, 10,  8,  9},
+    {10, 11,  9, 10},
+    {11, 12, 10, 11},
+    {12, 13, 11, 12},
+    {13, -1, 12, 13},
+    {14, 14, 13, 14},
+    {15, 15, 14, 15},
+    {16, 16, 15, 16},
+    {17, 17, 16, 17},
+    {-1, -1, 17, -1},
+    {-1, -1, -1, -1},
+    {-1, -1, -1, -1},
+    {-1, -1, -1, -1}};
 
 // one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + voff + IMM) -> LDS (m0base + M0ADD + 16*lane + IMM).
 // Three instructions: everything else (stage base, ring-slot base) is computed once per stage - an MFMA hides at most
@@ -432,8 +452,8 @@ k_layer(LayerArgs la) {
       tall_stage(acc1[0], acc1[1], I0);
       tall_stage(acc1[0], acc1[1], I1);
       // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2)).
-      // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: one element pair per
-      // block, 18 + 18 single instructions + 3 packs handed out slot by slot (GELU_A_LO / GELU_B_LO).
+      // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: four elements per pair of
+      // blocks, 4 x 18 single instructions + 6 packs handed out slot by slot (GELU_SCHED).
       u32x4 hcur[3], hn[3];
       {
         float xg[8];
@@ -454,36 +474,53 @@ k_layer(LayerArgs la) {
           const int kb = s2 * 2 + ks;
           const int kn = kb + 1;
 #pragma unroll
-          for (int tp = 0; tp < 4; ++tp) {
-            const int blk = ks * 4 + tp;
-            const bool nb = blk + 1 < 8;
-            const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
-            GeluState ge, go;
-            const float va = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 2 * tp] : 0.f;
-            const float vb = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 2 * tp + 1] : 0.f;
-            auto fill = [&](auto kc) __attribute__((always_inline)) {
-              constexpr int k = decltype(kc)::value;
-              if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
-              if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
-              if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
-              if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
-              if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
-              if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
-              if (k == 3) dma(blk, blk + 1);
-              if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
-              if (kb < 3) {
-                gelu_ops<GELU_A_LO[k], GELU_A_LO[k + 1]>(ge, va);
-                gelu_ops<GELU_B_LO[k], GELU_B_LO[k + 1]>(go, vb);
-                if (k == 10) {
-                  unsigned q1, q2, q3;
-                  gelu_pack(ge, go, q1, q2, q3);
-                  hn[0][tp] = q1;
-                  hn[1][tp] = q2;
-                  hn[2][tp] = q3;
+          for (int tpp = 0; tpp < 2; ++tpp) {
+            // two blocks share four GELU values: elements 4*tpp .. 4*tpp+3 of the NEXT k-block
+            GeluState g0, g1, g2, g3;
+            const float v0 = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 4 * tpp] : 0.f;
+            const float v1 = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 4 * tpp + 1] : 0.f;
+            const float v2 = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 4 * tpp + 2] : 0.f;
+            const float v3 = kb < 3 ? acc1[kn >> 1][8 * (kn & 1) + 4 * tpp + 3] : 0.f;
+            auto block = [&](auto halfc) __attribute__((always_inline)) {
+              constexpr int half = decltype(halfc)::value;
+              const int tp = 2 * tpp + half;
+              const int blk = ks * 4 + tp;
+              const bool nb = blk + 1 < 8;
+              const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+              auto fill = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
+                if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
+                if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
+                if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
+                if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
+                if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
+                if (k == 3) dma(blk, blk + 1);
+                if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
+                if (kb < 3) {
+                  constexpr int sl = half * 12 + k;
+                  gelu_maybe<GELU_SCHED[sl][0]>(g0, v0);
+                  gelu_maybe<GELU_SCHED[sl][1]>(g1, v1);
+                  gelu_maybe<GELU_SCHED[sl][2]>(g2, v2);
+                  gelu_maybe<GELU_SCHED[sl][3]>(g3, v3);
+                  if (sl == 21) {
+                    hn[0][2 * tpp] = __builtin_amdgcn_perm(gelu_ph(g1), gelu_ph(g0), 0x07060302);
+                    hn[0][2 * tpp + 1] = __builtin_amdgcn_perm(gelu_ph(g3), gelu_ph(g2), 0x07060302);
+                  }
+                  if (sl == 22) {
+                    hn[1][2 * tpp] = __builtin_amdgcn_perm(gelu_pm(g1), gelu_pm(g0), 0x07060302);
+                    hn[1][2 * tpp + 1] = __builtin_amdgcn_perm(gelu_pm(g3), gelu_pm(g2), 0x07060302);
+                  }
+                  if (sl == 23) {
+                    hn[2][2 * tpp] = __builtin_amdgcn_perm(gelu_pl(g1), gelu_pl(g0), 0x07060302);
+                    hn[2][2 * tpp + 1] = __builtin_amdgcn_perm(gelu_pl(g3), gelu_pl(g2), 0x07060302);
+                  }
                 }
-              }
+              };
+              DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2], fill)
             };
-            DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], hcur[0], hcur[1], hcur[2], fill)
+            block(I0);
+            block(I1);
           }
           if (kb < 3) {
 #pragma unroll
