@@ -89,6 +89,8 @@ struct Layout {
   size_t vpad_floats;
   unsigned char* wstream[DDP_MAX_LAYERS];               // layer kernel: weight stream (stage images) per layer
   float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
+  unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
+  float* tail_bias;                                     //           conv_seg bias, zero padded
   size_t total;
 };
 
@@ -234,6 +236,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     };
     o->vpad_floats = size_t(o->R) * (o->hh + 2) * (o->wh + 2) * 256;
     o->vpad = cv.take(o->vpad_floats);
+    o->tail_stream = reinterpret_cast<unsigned char*>(cv.take(size_t(8) * 48 * 1024 / sizeof(float)));
+    o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
     o->q_sb = takesb(o->M, 256);
     o->q1_sb = takesb(o->M, 256);
     o->s_sb = takesb(o->M, 256);
@@ -248,6 +252,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->q_sb = o->q1_sb = o->s_sb = o->h_sb = o->in_sb = nullptr;
     o->vpad = nullptr;
     o->vpad_floats = 0;
+    o->tail_stream = nullptr;
+    o->tail_bias = nullptr;
   }
   o->total = cv.off * sizeof(float);
 }
@@ -357,6 +363,16 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       DDP_TRY(launch_split_weights(lw.output_proj_w, 256, 256, 256, wr(o.wp_o[l]), st));
       DDP_TRY(launch_split_weights(lw.ffn0_w, 256, DDP_FFN, 256, wr(o.wp_f0[l]), st));
       DDP_TRY(launch_split_weights(lw.ffn1_w, DDP_FFN, 256, DDP_FFN, wr(o.wp_f1[l]), st));
+    }
+    if (c->task == DDP_TASK_SEG) {      // seg tail: conv_seg as tall stages of 64 classes, bias table
+      const int nch = (o.Kc + 63) / 64;
+      DDP_TRY(launch_build_stages(o.wp_head.p, o.wp_head.comp_stride, 256, o.Kc, 1, nch, 2, 0, 0, 1, 2, o.tail_stream, st));
+      if (hipMemsetAsync(o.tail_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          (w->head_b && hipMemcpyAsync(o.tail_bias, w->head_b, size_t(o.Kc) * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+                            hipSuccess)) {
+        set_error("tail bias copy failed");
+        return DDP_E_LAUNCH;
+      }
     }
     // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
     if (hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
@@ -583,6 +599,10 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     DDP_TRY(launch_nchw_to_tok(d_noise, o.mask, o.R, 256, o.N, st));
   }
 
+  // seg + DDIM on the bf16x3 engine: conv_seg, argmax, softmax accumulation, x0 LUT and the DDIM update run as the
+  // "tail" mode of the layer kernel, which leaves m_{t_next} as the SB operand of the next step's concat-conv
+  const bool seg_tail = o.b3 && b3_layer_fused_enabled() && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
+                        o.h == o.hh && o.w == o.wh;
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
@@ -591,7 +611,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.s, o.B, o.r, o.N, st));
       DDP_TRY(publish_q(o, o.s, st));
     } else {
-      if (o.b3) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
+      if (o.b3 && !(seg_tail && s > 0)) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
       if (cfg->task == DDP_TASK_BEV) {
         if (o.b3)
           DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256, 256, st,
@@ -610,7 +630,25 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       }
     }
     DDP_TRY(encoder_forward(weights, o, aff, st));
-    if (cfg->task == DDP_TASK_SEG) {
+    if (seg_tail) {
+      TailLaunch tl;
+      tl.Q = o.q_sb;
+      tl.stream = o.tail_stream;
+      tl.bias_ext = o.tail_bias;
+      tl.lut = o.lut;
+      // accumulation: softmax summed over the steps; otherwise the last step's scores are the output
+      tl.prob = cfg->accumulation ? o.prob : o.logits;
+      tl.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : (s == o.K - 1 ? 3 : 0);
+      tl.mask_sb = o.in_sb;
+      tl.M = M;
+      tl.num_classes = o.Kc;
+      tl.ldl = o.ldl;
+      tl.alpha = sp.alpha;
+      tl.sigma = sp.sigma;
+      tl.alpha_next = sp.alpha_next;
+      tl.sigma_next = sp.sigma_next;
+      DDP_TRY(launch_b3_tail(tl, st));
+    } else if (cfg->task == DDP_TASK_SEG) {
       if (o.b3)
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256, st,
                                  TAG_HEAD));

@@ -172,6 +172,55 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   prof_end(TAG_FC2_LN, st);
   return check_launch("b3::k_layer");
 }
+namespace {
+template <int NCH>
+int launch_tail_t(const b3::LayerArgs& la, int grid, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, 1, NCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::LYR_LDS_B));
+    attr_done = true;
+  }
+  prof_begin(TAG_HEAD, st);
+  hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, 1, NCH>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  prof_end(TAG_HEAD, st);
+  return check_launch("b3::k_layer (seg tail)");
+}
+}  // namespace
+
+int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
+  if (a.M <= 0) return DDP_OK;
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  la.Q = const_cast<unsigned short*>(a.Q);
+  la.stream = a.stream;
+  la.bias_ext = a.bias_ext;
+  la.M = a.M;
+  la.lut = a.lut;
+  la.prob = a.prob;
+  la.mask_sb = a.mask_sb;
+  la.num_classes = a.num_classes;
+  la.ldl = a.ldl;
+  la.prob_mode = a.prob_mode;
+  la.alpha = a.alpha;
+  la.sigma = a.sigma;
+  la.alpha_next = a.alpha_next;
+  la.sigma_next = a.sigma_next;
+  int n_cu = 0, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  const int nch = (a.num_classes + 63) / 64;
+  switch (nch) {
+    case 1: return launch_tail_t<1>(la, grid, st);
+    case 2: return launch_tail_t<2>(la, grid, st);
+    case 3: return launch_tail_t<3>(la, grid, st);
+    case 4: return launch_tail_t<4>(la, grid, st);
+    default: set_error("seg tail: %d classes (1..256)", a.num_classes); return DDP_E_BADCFG;
+  }
+}
+
 size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }
 int b3_layer_bias_floats() { return b3::LYR_BIAS_N; }
 

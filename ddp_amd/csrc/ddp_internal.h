@@ -71,6 +71,18 @@ struct LayerLaunch {
   int n_tok, w;
 };
 int launch_b3_layer(const LayerLaunch& a, hipStream_t st);
+// seg tail on the layer kernel's machinery: conv_seg + argmax + softmax accumulation + x0 LUT + DDIM update (SB in / out)
+struct TailLaunch {
+  const unsigned short* Q;      // SB decoder output
+  const unsigned char* stream;  // 2 * chunks stage images of conv_seg (64 classes per chunk)
+  const float* bias_ext;        // conv_seg bias, zero padded to b3_layer_bias_floats()
+  const float* lut;
+  float* prob;
+  unsigned short* mask_sb;
+  int M, num_classes, ldl, prob_mode;
+  float alpha, sigma, alpha_next, sigma_next;
+};
+int launch_b3_tail(const TailLaunch& a, hipStream_t st);
 size_t b3_layer_stream_bytes();
 int b3_layer_bias_floats();
 bool b3_layer_fused_enabled();

@@ -68,6 +68,12 @@ struct LayerArgs {
   const float* py;               // next layer's positional tables (h,96) / (w,96), bias folded in
   const float* px;
   int n_tok, w;
+  // MODE 1 (seg tail): conv_seg + x0 projection + DDIM update + softmax accumulation on the tokens of Q
+  const float* lut;              // (num_classes + 1, 256): (sigmoid(embedding) * 2 - 1) * bit_scale
+  float* prob;                   // (M, ldl) accumulated softmax / last-step scores
+  unsigned short* mask_sb;       // SB noisy map m_t (256 ch): read, replaced by m_{t_next}
+  int num_classes, ldl, prob_mode;   // prob_mode: 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = scores
+  float alpha, sigma, alpha_next, sigma_next;
 };
 
 // vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
@@ -163,7 +169,12 @@ __device__ __forceinline__ void stream_piece(unsigned long long base, unsigned v
       : "memory", "scc");
 }
 
-template <int TAG>
+// MODE 0: the decoder layer (output_proj + LN0, FFN + LN1 + FiLM, next layer's projections).
+// MODE 1: the tail of a segmentation step on the same machinery: scores = conv_seg(q) as NCH chunks of 64 classes,
+//         then - per token, in registers - argmax, softmax accumulation, x0 = LUT[argmax], DDIM update of the noisy
+//         map (read and written as SB: the next step's concat-conv operand).  Replaces conv_seg GEMM + k_seg_update +
+//         k_row_to_sb (segmentors/ddp.py:235-245; decode_head.py:133).
+template <int TAG, int MODE = 0, int NCH = 0>
 __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -178,7 +189,7 @@ k_layer(LayerArgs la) {
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
   const unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const int n_stages = la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN;
+  const int n_stages = MODE == 1 ? 2 * NCH : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
   unsigned mb = 0;                                             // ring-slot LDS base (+ this wave's share)
@@ -254,12 +265,14 @@ k_layer(LayerArgs la) {
   {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + LYR_BIAS_OFF);
     for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
-    tab[LYR_T_BO + tid] = la.bo[tid];
-    tab[LYR_T_GA0 + tid] = la.ga0[tid];
-    tab[LYR_T_BE0 + tid] = la.be0[tid];
-    tab[LYR_T_B2 + tid] = la.b2[tid];
-    tab[LYR_T_GA1 + tid] = la.ga1[tid];
-    tab[LYR_T_BE1 + tid] = la.be1[tid];
+    if constexpr (MODE == 0) {
+      tab[LYR_T_BO + tid] = la.bo[tid];
+      tab[LYR_T_GA0 + tid] = la.ga0[tid];
+      tab[LYR_T_BE0 + tid] = la.be0[tid];
+      tab[LYR_T_B2 + tid] = la.b2[tid];
+      tab[LYR_T_GA1 + tid] = la.ga1[tid];
+      tab[LYR_T_BE1 + tid] = la.be1[tid];
+    }
   }
   wait_vm0();
   __syncthreads();
@@ -328,6 +341,117 @@ k_layer(LayerArgs la) {
     const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
     char* qs = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
 
+    if constexpr (MODE == 1) {
+      // ---- seg tail: q fragments of this tile (the layer output), scores = conv_seg(q), per-token update
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+      f32x16 lg[NCH > 0 ? NCH : 1][2];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        bias_init(lg[c], c);
+        tall_stage(lg[c][0], lg[c][1], I0);
+        tall_stage(lg[c][0], lg[c][1], I1);
+      }
+      const int m = m_base + j;
+      const bool valid = m < M;
+      const int K = la.num_classes;
+      // argmax over the token's classes: this lane holds classes 64c + 32t + 8g + 4h + e, its partner (lane ^ 32) the
+      // other half; first maximum wins (torch.argmax)
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float v = lg[c][t][r];
+            if (cls < K && v > best) {
+              best = v;
+              bi = cls;
+            }
+          }
+      {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
+      if (!valid || bi >= K) bi = 0;
+      if (la.prob_mode == 1 || la.prob_mode == 2) {          // softmax over the classes, accumulated over the steps
+        float ssum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+              const float e = cls < K ? __builtin_amdgcn_exp2f((lg[c][t][r] - best) * 1.44269504088896340736f) : 0.f;
+              lg[c][t][r] = e;
+              ssum += e;
+            }
+        ssum += __shfl_xor(ssum, 32, 64);
+        const float inv = 1.0f / ssum;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[c][t][r] = lg[c][t][r] * inv;
+      }
+      if (valid && la.prob_mode != 0) {
+        float* pr = la.prob + size_t(m) * la.ldl + 4 * h;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cls0 = c * 64 + t * 32 + 8 * g;
+              if (cls0 + 4 * h < K) {                          // (rows are padded to ldl >= roundup(K, 32))
+                f32x4 v = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
+                f32x4* d = reinterpret_cast<f32x4*>(pr + cls0);
+                if (la.prob_mode == 2) v = v + *d;
+                *d = v;
+              }
+            }
+      }
+      // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out
+      {
+        const float* x0row = la.lut + size_t(bi) * 256 + 4 * h;
+        char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
+        const float inv_sig = 1.0f / fmaxf(la.sigma, 1e-8f);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          const u32x4 p1 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 0) * 1024);
+          const u32x4 p2 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 1) * 1024);
+          const u32x4 p3 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 2) * 1024);
+          const f32x4 xlo = *reinterpret_cast<const f32x4*>(x0row + 16 * b);
+          const f32x4 xhi = *reinterpret_cast<const f32x4*>(x0row + 16 * b + 8);
+          float mn[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float mt = (bf_elem(p1, u) + bf_elem(p2, u)) + bf_elem(p3, u);
+            const float x0 = u < 4 ? xlo[u] : xhi[u - 4];
+            const float pn = (mt - la.alpha * x0) * inv_sig;
+            mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
+          }
+          u32x4 q1, q2, q3;
+          split8(mn, q1, q2, q3);
+          *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
+          *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
+          *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
+        }
+      }
+    }
+    if constexpr (MODE == 0) {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead)
     u32x4 sc[2][3], sn[2][3];
 #pragma unroll
@@ -632,6 +756,7 @@ k_layer(LayerArgs la) {
           }
         }
       }
+    }
     }
   }
 #undef DDP_LYR_BLOCK
