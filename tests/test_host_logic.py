@@ -183,3 +183,44 @@ def test_self_aligned_ddp_resolves_to_the_same_inference_class():
     assert cls is ddp_amd.SelfAlignedDDP and issubclass(cls, ddp_amd.DDP)
     for m in ('ddim_sample', 'ddpm_sample', 'encode_decode', 'simple_test'):
         assert getattr(cls, m) is getattr(ddp_amd.DDP, m)
+
+
+def test_neck_and_fcn_head_state_dict_layouts():
+    """the drop-in FPN / MultiStageMerging / FCNHeadWithTime classes expose exactly the reference's parameter and buffer
+    names (necks/fpn.py:119-134, necks/multi_stage_merging.py:28-37, decode_heads/fcn_head_with_time.py:100-175,
+    242-283): strict load both ways, no GPU needed"""
+    inc = [96, 192, 384, 768]
+    fpn = ddp_amd.FPN(in_channels=inc, out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32), num_outs=4)
+    sd = synthetic.make_fpn_state_dict(inc, 0)
+    assert {k: tuple(v.shape) for k, v in fpn.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    fpn.load_state_dict(sd, strict=True)
+    msm = ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None)
+    sdm = synthetic.make_neck_state_dict(0)
+    assert {k: tuple(v.shape) for k, v in msm.state_dict().items()} == {k: tuple(v.shape) for k, v in sdm.items()}
+    msm.load_state_dict(sdm, strict=True)
+    for with_norm, concat in ((True, True), (False, False)):
+        head = ddp_amd.FCNHeadWithTime(num_convs=2, concat_input=concat, in_channels=256, channels=256, num_classes=19,
+                                       in_index=0, norm_cfg=dict(type='SyncBN') if with_norm else None)
+        sdh = synthetic.make_fcn_state_dict(2, 19, with_norm, concat, 0)
+        assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == {k: tuple(v.shape) for k, v in sdh.items()}
+        head.load_state_dict(sdh, strict=True)
+    # configurations outside the DDP configs fail loudly instead of silently computing something else
+    with pytest.raises(NotImplementedError):
+        ddp_amd.FPN(in_channels=inc, out_channels=256, num_outs=5, norm_cfg=dict(type='GN', num_groups=32))
+    with pytest.raises(NotImplementedError):
+        ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=3, norm_cfg=dict(type='GN', num_groups=32))
+    with pytest.raises(NotImplementedError):
+        ddp_amd.FCNHeadWithTime(num_convs=1, in_channels=128, channels=128, num_classes=19)
+    # no CPU path
+    with pytest.raises(_lib.DdpError):
+        msm([torch.zeros(1, 256, 4, 4)] * 4)
+
+
+def test_neck_chain_resolves_from_the_reference_config_dict():
+    """configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py:39-54: neck=[FPN, MultiStageMerging] by registry name"""
+    cfg = seg_cfg(neck=[dict(type='FPN', in_channels=[96, 192, 384, 768], out_channels=256, act_cfg=None,
+                             norm_cfg=dict(type='GN', num_groups=32), num_outs=4),
+                        dict(type='MultiStageMerging', in_channels=[256, 256, 256, 256], out_channels=256, kernel_size=1,
+                             norm_cfg=dict(type='GN', num_groups=32), act_cfg=None)])
+    model = ddp_amd.build_segmentor(cfg)
+    assert [type(m).__name__ for m in model.neck] == ['FPN', 'MultiStageMerging']
