@@ -28,7 +28,12 @@
 //     NOTHING is issued between them, and loads / GELU / DMA have to sit somewhere;
 //   * a weight fragment is re-read into its own registers as soon as its last MFMA of the block has issued
 //     (w2 after 2 MFMAs, w1 after 6, w0 after 12 - terms ordered for that), >= 6 MFMAs before its next use;
-//   * the 12 DMA pieces of a stage are spread over its 8 MFMA blocks; GELU of k-block n+1 runs under k-block n.
+//   * the 12 DMA pieces of a stage are spread over its 8 MFMA blocks;
+//   * behind one MFMA a single wave hides 5 independent instructions but only 3 of one dependency chain
+//     (scripts/ubench/mfma_fill.hip): every MFMA has its own filler slot, and GELU + split of k-block n+1 is handed
+//     out to the slots of k-block n as single instructions of four values at a time (GELU_SCHED).
+// The same machinery in MODE 1 is the tail of a segmentation step (conv_seg, argmax, softmax accumulation, x0 LUT,
+// DDIM update of the noisy map kept as SB).
 #pragma once
 #include <type_traits>
 
