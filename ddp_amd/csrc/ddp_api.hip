@@ -1016,9 +1016,10 @@ static int fpn_layout(const ddp_fpn_level* lv, int batch, char* base, FpnLayout*
     }
     const size_t M = size_t(batch) * v.h * v.w, Mp = (M + 255) / 256 * 256;
     o->lat[l] = reinterpret_cast<float*>(take(Mp * 256 * 4));
-    const size_t kmax = v.in_channels > 2304 ? v.in_channels : 2304;
+    const size_t kmax = v.in_channels > 2304 ? v.in_channels : 2304;       // weight rows: lateral C_l, 3x3 conv 9*256
+    const size_t amax = v.in_channels > 256 ? v.in_channels : 256;         // SB operand: lateral C_l, 3x3 conv 256
     if (M * v.in_channels > max_tok) max_tok = M * v.in_channels;
-    if (Mp * kmax > max_a) max_a = Mp * kmax;
+    if (Mp * amax > max_a) max_a = Mp * amax;
     if (kmax > max_w) max_w = kmax;
     if (Mp > Mp0) Mp0 = Mp;
     const size_t ch = (size_t(v.h) * v.w + 255) / 256;
@@ -1078,17 +1079,17 @@ int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_i
   for (int l = 3; l > 0; --l)
     DDP_TRY(launch_upsample_nearest_add(o.lat[l - 1], o.lat[l], batch, levels[l - 1].h, levels[l - 1].w, levels[l].h,
                                         levels[l].w, st));
-  // outputs (:189-191): 3x3 conv (GEMM over im2col, K = 2304) + GroupNorm -> NCHW
+  // outputs (:189-191): 3x3 conv (implicit GEMM, K = 2304) + GroupNorm -> NCHW
   for (int l = 0; l < 4; ++l) {
     const ddp_fpn_level& v = levels[l];
     const int N = v.h * v.w, M = batch * N;
     DDP_TRY(launch_pack_conv3x3_scaled(v.out_w, nullptr, o.wpack, 256, 256, st));
     DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
-    DDP_TRY(launch_im2col3x3_sb(o.lat[l], o.a_sb, batch, v.h, v.w, 1, st));
+    DDP_TRY(launch_row_to_sb(o.lat[l], 256, o.a_sb, M, 256, st));
     SplitW w;
     w.p = o.wsplit;
     w.comp_stride = size_t(256) * 2304;
-    DDP_TRY(launch_b3_linear_act(o.a_sb, w, nullptr, o.y, 256, M, 2304, 0, st));
+    DDP_TRY(launch_b3_conv3x3(o.a_sb, w, nullptr, o.y, 256, batch, v.h, v.w, 1, 0, st));
     DDP_TRY(launch_group_norm_nchw(o.y, o.partial, o.stats, v.out_gn_w, v.out_gn_b, d_out[l], batch, N, 1e-5f, st));
   }
   return DDP_OK;
@@ -1116,7 +1117,7 @@ static int fcn_layout(int maps, int h, int w, int K, char* base, FcnLayout* o) {
   o->ldl = (K + 31) / 32 * 32;
   o->x0 = reinterpret_cast<float*>(take(Mp * 256 * 4));
   o->x1 = reinterpret_cast<float*>(take(Mp * 256 * 4));
-  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 2304 * 6));
+  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 256 * 6));
   o->wpack = reinterpret_cast<float*>(take(size_t(256) * 2304 * 4));
   o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 2304 * 2));
   o->film = reinterpret_cast<float*>(take(512 * 4));
@@ -1173,11 +1174,11 @@ int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation,
     DDP_TRY(launch_fcn_fold(c.bn_w, c.bn_b, c.bn_mean, c.bn_var, c.bn_eps, c.conv_b, film, o.aff, o.aff + 256, st));
     DDP_TRY(launch_pack_conv3x3_scaled(c.conv_w, o.aff, o.wpack, 256, 256, st));
     DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
-    DDP_TRY(launch_im2col3x3_sb(cur, o.a_sb, maps, h, w, dilation, st));
+    DDP_TRY(launch_row_to_sb(cur, 256, o.a_sb, M, 256, st));
     SplitW wsp;
     wsp.p = o.wsplit;
     wsp.comp_stride = size_t(256) * 2304;
-    DDP_TRY(launch_b3_linear_act(o.a_sb, wsp, o.aff + 256, nxt, 256, M, 2304, 2, st));
+    DDP_TRY(launch_b3_conv3x3(o.a_sb, wsp, o.aff + 256, nxt, 256, maps, h, w, dilation, 2, st));
     float* t = cur;
     cur = nxt;
     nxt = t;

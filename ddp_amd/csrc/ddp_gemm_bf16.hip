@@ -43,6 +43,7 @@ b3::Args make_b3(const unsigned short* A_sb, const SplitW& w, const float* bias,
   a.K = K;
   a.n_tiles_n = 1;
   a.acc_bias = bias;
+  a.conv_h = a.conv_w = a.conv_dil = 0;
   return a;
 }
 
@@ -70,6 +71,36 @@ int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* b
   if (tag == TAG_VALUE) return launch_b3<8, TAG_VALUE>(ga, e, st);
   if (tag == TAG_XPROJ) return launch_b3<8, TAG_XPROJ>(ga, e, st);
   return launch_b3<8, TAG_HEAD>(ga, e, st);
+}
+
+// 3x3 convolution (256 -> 256 channels, zero padding) as an implicit GEMM over the SB input: out (M,256) row-major =
+// act(conv + bias); weights packed tap-major (256, 9*256) and split
+int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* bias, float* out, int ldo, int maps, int h,
+                      int wd, int dilation, int act, hipStream_t st) {
+  EpiRow e;
+  e.add = nullptr;
+  e.ld_add = 0;
+  e.rn = 0;
+  e.n_tok = 0;
+  e.out = out;
+  e.ldo = ldo;
+  e.n_valid = 256;
+  e.gelu = act;
+  b3::Args ga = make_b3(X_sb, w, bias, maps * h * wd, 256, 2304);
+  ga.conv_h = h;
+  ga.conv_w = wd;
+  ga.conv_dil = dilation;
+  ga.n_tiles_n = 1;
+  constexpr size_t lds = b3::lds_bytes<8, EpiRow>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_gemm<8, EpiRow, TAG_GENERIC, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    attr_done = true;
+  }
+  if (ga.M <= 0) return DDP_OK;
+  hipLaunchKernelGGL((b3::k_gemm<8, EpiRow, TAG_GENERIC, true>), dim3(b3::grid(ga.M, 1)), dim3(b3::THREADS), lds, st, ga, e);
+  return check_launch("b3::k_gemm (conv3x3)");
 }
 
 // same, with an activation on the way out (act: 0 none, 1 GELU, 2 ReLU); N = 256

@@ -44,6 +44,8 @@ struct SplitW {
 };
 int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                      int rn, int n_tok, float* out, int ldo, int M, int N, int K, hipStream_t st, int tag);
+int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* bias, float* out, int ldo, int maps, int h,
+                      int wd, int dilation, int act, hipStream_t st);
 int launch_b3_linear_act(const unsigned short* A_sb, const SplitW& w, const float* bias, float* out, int ldo, int M, int K,
                          int act, hipStream_t st);
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
@@ -150,8 +152,7 @@ int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st);
 int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
                            int B, int N, float eps, hipStream_t st);
 int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf, int wf, int hc, int wc, hipStream_t st);
-// 3x3 convolution as a GEMM (FCNHeadWithTime, FPN): im2col straight into the SB operand, weights packed tap-major
-int launch_im2col3x3_sb(const float* x_rows, unsigned short* out_sb, int R, int h, int w, int dilation, hipStream_t st);
+// 3x3 convolution as an implicit GEMM (FCNHeadWithTime, FPN): weights packed tap-major, launch_b3_conv3x3
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,
                     const float* conv_bias, const float* film, float* scale, float* shift, hipStream_t st);

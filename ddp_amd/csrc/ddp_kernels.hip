@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // FPN neck pieces (necks/fpn.py:163-213): lateral 1x1 conv + GN, top-down nearest upsample + add,
-// output 3x3 conv + GN.  The convolutions are bf16x3 GEMMs (the 3x3 ones over k_im2col3x3_sb); these two kernels are
+// output 3x3 conv + GN.  The convolutions are bf16x3 GEMMs (the 3x3 ones implicit: b3::k_gemm<..., CONV>); these two kernels are
 // the token-major GroupNorm apply and the top-down step.
 // ------------------------------------------------------------------------------------------------
 // out[n][c] = (y[n][c] - mean) * rstd * gamma[c] + beta[c], token-major (B, N, 256) in and out; one wave per token
@@ -704,62 +704,9 @@ __global__ void __launch_bounds__(256) k_upsample_nearest_add(float* __restrict_
 // FCNHeadWithTime (decode_heads/fcn_head_with_time.py:205-225,285-305): each ConvWithTimeModule is
 // conv3x3 -> norm -> x*(scale+1)+shift (FiLM from the time embedding) -> ReLU.  In eval mode the norm and the FiLM are
 // one per-channel affine: the scale goes into the (re-packed) weights, the shift into the accumulator bias, ReLU into
-// the GEMM epilogue - the convolution itself is ONE bf16x3 GEMM with K = 9*256 over an im2col operand that is
-// written directly in SB form.
+// the GEMM epilogue - the convolution itself is ONE bf16x3 implicit GEMM with K = 9*256 (b3::k_gemm<..., CONV>: every
+// lane fetches the SB slot of its tap-shifted source token; no im2col buffer).
 // ------------------------------------------------------------------------------------------------
-// x (R*N, 256) row-major -> SB with K = 2304, k = tap*256 + c, tap = ky*3 + kx, zero padding.  A block owns one
-// 32-token group; per tap each wave copies 4 neighbour rows into the LDS tile, then the block emits 16 K16 blocks.
-__global__ void __launch_bounds__(64 * GSB_WAVES) k_im2col3x3_sb(const float* __restrict__ x, unsigned short* __restrict__ out_sb,
-                                                                   int rows, int h, int w, int dil) {
-  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int m_base = blockIdx.x * 32;
-  const int N = h * w;
-  char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 2304 * 192;
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
-#pragma unroll
-    for (int it = 0; it < 32 / GSB_WAVES; ++it) {
-      const int jj = wave * (32 / GSB_WAVES) + it;
-      const int m = m_base + jj;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < rows) {
-        const int b = m / N, n = m - b * N;
-        const int i = n / w + dy, j = n % w + dx;
-        if (i >= 0 && i < h && j >= 0 && j < w) v = *reinterpret_cast<const f32x4*>(x + (size_t(b) * N + i * w + j) * 256 + lane * 4);
-      }
-      *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + lane * 4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16 / GSB_WAVES; ++r) {
-      const int item = r * 64 * GSB_WAVES + threadIdx.x;
-      const int b = item >> 6, l2 = item & 63;
-      const int j = l2 & 31, hh = l2 >> 5;
-      const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
-      const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
-      unsigned short p[3][8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        split3(lo4[u], p[0][u], p[1][u], p[2][u]);
-        split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
-      }
-      char* dst = gbase + size_t(tap * 16 + b) * 3 * 1024 + l2 * 16;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        uint4 v;
-        v.x = p[c][0] | (unsigned(p[c][1]) << 16);
-        v.y = p[c][2] | (unsigned(p[c][3]) << 16);
-        v.z = p[c][4] | (unsigned(p[c][5]) << 16);
-        v.w = p[c][6] | (unsigned(p[c][7]) << 16);
-        *reinterpret_cast<uint4*>(dst + c * 1024) = v;
-      }
-    }
-    __syncthreads();
-  }
-}
 // conv.weight (cout, cin, 3, 3) -> (cout, 9*cin) tap-major rows, each row scaled by scale[cout] (nullptr: 1)
 __global__ void k_pack_conv3x3_scaled(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
                                       int cout, int cin) {
@@ -1221,11 +1168,6 @@ int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf,
   const int rows = B * hf * wf;
   hipLaunchKernelGGL(k_upsample_nearest_add, dim3(cdiv(rows, 4)), dim3(256), 0, st, fine, coarse, hf, wf, hc, wc, rows);
   return check_launch("k_upsample_nearest_add");
-}
-int launch_im2col3x3_sb(const float* x_rows, unsigned short* out_sb, int R, int h, int w, int dilation, hipStream_t st) {
-  const int rows = R * h * w;
-  hipLaunchKernelGGL(k_im2col3x3_sb, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, x_rows, out_sb, rows, h, w, dilation);
-  return check_launch("k_im2col3x3_sb");
 }
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_conv3x3_scaled, dim3(cdiv(long(cout) * 9 * cin, 256)), dim3(256), 0, st, w, scale, out, cout, cin);

@@ -63,6 +63,9 @@ struct Args {
   int M, N, K;
   int n_tiles_n;
   const float* acc_bias;
+  // CONV (3x3 convolution as an implicit GEMM): A is the 256-channel SB input of (M / (h*w)) maps of h x w tokens,
+  // K = 9 * 256 with k = tap * 256 + c, tap = ky * 3 + kx, zero padding, dilation dil
+  int conv_h, conv_w, conv_dil;
 };
 
 __device__ __forceinline__ f32x16 mma(u32x4 w, u32x4 a, f32x16 c) {
@@ -106,7 +109,10 @@ __device__ __forceinline__ void store_tile_sb(const f32x16& a, unsigned short* s
   }
 }
 
-template <int NT, class Epi, int TAG>
+// CONV = true: the A fragment of k-tile kt is not a slice of the wave's own token group but the 32 tokens shifted by
+// the tap's (dy, dx): every lane fetches the 16-B slot of ITS source token (a rotated, at most two-group range: still
+// two contiguous segments per load), lanes whose source falls outside the map read zeros - no im2col buffer.
+template <int NT, class Epi, int TAG, bool CONV = false>
 __global__ void __launch_bounds__(THREADS, 2)
 k_gemm(Args ga, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,9 +163,41 @@ k_gemm(Args ga, Epi epi) {
   };
 
   // activation fragments: SB buffer, this wave's 32-token group
-  const char* a_src = reinterpret_cast<const char*>(ga.A) + (size_t(m0 >> 5) + wave) * ga.K * 192 + lane * 16;
-  auto a_frag = [&](int kt, int ks, int comp) -> u32x4 {
-    return *reinterpret_cast<const u32x4*>(a_src + ((kt * 2 + ks) * 3 + comp) * 1024);
+  const char* a_src = reinterpret_cast<const char*>(ga.A) + (size_t(m0 >> 5) + wave) * (CONV ? 256 : ga.K) * 192 + lane * 16;
+  // CONV: this lane's output token (b, ci, cj)
+  int cm = 0, ci = 0, cj = 0;
+  if constexpr (CONV) {
+    const int m = m0 + wave * 32 + j;
+    cm = m < M ? m : -1;
+    const int mm = m < M ? m : M - 1;
+    const int n_img = ga.conv_h * ga.conv_w;
+    const int n = mm - (mm / n_img) * n_img;
+    ci = n / ga.conv_w;
+    cj = n - ci * ga.conv_w;
+  }
+  struct ASrc {
+    const char* p;     // address of (K16 block 0, piece 0) of this lane's source slot
+    bool ok;
+  };
+  auto a_source = [&](int kt) -> ASrc {
+    ASrc r;
+    if constexpr (CONV) {
+      const int tap = kt >> 3;                     // 8 k-tiles (256 channels) per tap
+      const int dy = (tap / 3 - 1) * ga.conv_dil, dx = (tap - (tap / 3) * 3 - 1) * ga.conv_dil;
+      r.ok = cm >= 0 && ci + dy >= 0 && ci + dy < ga.conv_h && cj + dx >= 0 && cj + dx < ga.conv_w;
+      const int ms = r.ok ? cm + dy * ga.conv_w + dx : 0;
+      r.p = reinterpret_cast<const char*>(ga.A) + size_t(ms >> 5) * 256 * 192 + (h * 32 + (ms & 31)) * 16 +
+            size_t((kt & 7) * 2) * 3 * 1024;
+    } else {
+      r.p = a_src + size_t(kt) * 2 * 3 * 1024;
+      r.ok = true;
+    }
+    return r;
+  };
+  auto a_frag = [&](const ASrc& sp, int ks, int comp) -> u32x4 {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (!CONV || sp.ok) v = *reinterpret_cast<const u32x4*>(sp.p + (ks * 3 + comp) * 1024);
+    return v;
   };
 
   f32x16 acc[NT];
@@ -185,10 +223,13 @@ k_gemm(Args ga, Epi epi) {
   const int nk = ga.K / BK;
   u32x4 a_cur[2][3], a_nxt[2][3];
   dma_w(0, 0);
+  {
+    const ASrc s0 = a_source(0);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a_cur[ks][c] = a_frag(0, ks, c);
+      for (int c = 0; c < 3; ++c) a_cur[ks][c] = a_frag(s0, ks, c);
+  }
   wait_vm0();
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -206,10 +247,11 @@ k_gemm(Args ga, Epi epi) {
   auto step = [&](u32x4 (&ac)[2][3], u32x4 (&an)[2][3], int kt, int st) {
     const int k1 = kt + 1 < nk ? kt + 1 : nk - 1;
     dma_w(k1, st ^ 1);
+    const ASrc s1 = a_source(k1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) an[ks][c] = a_frag(k1, ks, c);
+      for (int c = 0; c < 3; ++c) an[ks][c] = a_frag(s1, ks, c);
     u32x4 w[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) w[c] = frag(st, c, 0, 0);
