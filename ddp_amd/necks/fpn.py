@@ -4,8 +4,8 @@
 
 Same registry name, constructor kwargs, ``state_dict`` keys (``lateral_convs.l.conv.weight``, ``lateral_convs.l.gn.*``,
 ``fpn_convs.l.conv.weight``, ``fpn_convs.l.gn.*``) and ``forward(inputs) -> tuple`` as the reference class; the work
-happens in ``ddp_neck_fpn`` of libddp_mi355x.so (1x1 and 3x3 convolutions as bf16x3 GEMMs, the latter over an im2col
-operand written directly in SB form; deterministic two-stage GroupNorm).  CUDA tensors only - no CPU path.
+happens in ``ddp_neck_fpn`` of libddp_mi355x.so (1x1 and 3x3 convolutions as bf16x3 GEMMs, the latter implicit - taps
+fetched from the SB activation inside the kernel; deterministic two-stage GroupNorm).  CUDA tensors only - no CPU path.
 """
 import ctypes as C
 
