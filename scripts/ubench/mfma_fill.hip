@@ -7,6 +7,7 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 template <int K, int KIND>
 __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, float* sink, int iters) {
@@ -18,6 +19,9 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, float* sink
   float f[12];
   for (int i = 0; i < 12; ++i) f[i] = float(threadIdx.x + i);
   u32x4 lr[4] = {};
+  f32x2 p[6];
+  for (int i = 0; i < 6; ++i) p[i] = f32x2{float(threadIdx.x + i), float(i)};
+  const f32x2 kc = {1.0009765625f, 0.f};
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -39,8 +43,16 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, float* sink
           asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[q & 1]));
         } else if (KIND == 5) {          // three interleaved dependent chains (distance 3)
           asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[q % 3]));
-        } else {                         // transcendental (quarter rate): v_exp_f32, independent
+        } else if (KIND == 6) {          // transcendental (quarter rate): v_exp_f32, independent
           asm volatile("v_exp_f32 %0, %0" : "+v"(f[q % 12]));
+        } else if (KIND == 7) {          // packed fp32 (two values per lane and instruction), independent
+          asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[q % 6]));
+        } else if (KIND == 8) {          // packed fp32, two dependent chains
+          asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[q & 1]));
+        } else if (KIND == 9) {          // packed fp32 with an SGPR-pair constant operand (splat through op_sel_hi)
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %0 op_sel_hi:[1,0,1]" : "+v"(p[q % 6]) : "s"(kc));
+        } else {                         // packed multiply
+          asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[q % 6]));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -52,6 +64,7 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, float* sink
   for (int i = 0; i < 16; ++i) s += a[i] + b[i];
   for (int i = 0; i < 12; ++i) s += f[i];
   for (int i = 0; i < 4; ++i) s += float(lr[i][0]);
+  for (int i = 0; i < 6; ++i) s += p[i][0] + p[i][1];
   sink[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
@@ -82,5 +95,9 @@ int main() {
   sweep<4>("v_fma_f32, two dependent chains interleaved", d_out, d_sink);
   sweep<5>("v_fma_f32, three dependent chains interleaved", d_out, d_sink);
   sweep<6>("v_exp_f32 (independent)", d_out, d_sink);
+  sweep<7>("v_pk_fma_f32 (independent)", d_out, d_sink);
+  sweep<8>("v_pk_fma_f32, two dependent chains interleaved", d_out, d_sink);
+  sweep<9>("v_pk_fma_f32 with SGPR constant (op_sel_hi splat)", d_out, d_sink);
+  sweep<10>("v_pk_mul_f32 (independent)", d_out, d_sink);
   return 0;
 }
