@@ -13,6 +13,8 @@ from .decode_heads.fcn_head_with_time import FCNHeadWithTime  # noqa: F401
 from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime  # noqa: F401
 from .bev.ddp import DDP as BEVDDP, BEVDeformableHeadWithTime  # noqa: F401
 from .necks import FPN, MultiStageMerging  # noqa: F401
+from .apis import single_gpu_test, multi_gpu_test, collect_results  # noqa: F401
 
 __all__ = ['DDP', 'SelfAlignedDDP', 'DeformableHeadWithTime', 'FCNHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
-           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg']
+           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg',
+           'single_gpu_test', 'multi_gpu_test', 'collect_results']

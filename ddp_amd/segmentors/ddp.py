@@ -176,9 +176,22 @@ class DDP(nn.Module, _SamplerMixin):
                                       align_corners=self.align_corners)
         return seg_logit
 
+    @staticmethod
+    def _epilogue_args(meta, rescale):
+        crop = out_size = flip = None
+        if meta:
+            if rescale:
+                crop = tuple(meta['img_shape'][:2])
+                out_size = tuple(meta['ori_shape'][:2])
+            if meta.get('flip', False):
+                flip = meta.get('flip_direction', 'horizontal')
+        return crop, out_size, flip
+
     def simple_test(self, img, img_meta=None, rescale=True):
         """encoder_decoder.py:250-304 (mode='whole'), post-loop epilogue fused into one kernel:
-        the (1,K,H,W) resized scores / probabilities of the reference are never materialised."""
+        the (1,K,H,W) resized scores / probabilities of the reference are never materialised.  ``img`` may hold
+        b >= 1 images (§8 f4): the loop runs once on the whole batch with independent noise per image, and every
+        image gets the crop / rescale / flip of its OWN ``img_meta`` entry (one epilogue launch per distinct geometry)."""
         from ..engine import seg_postprocess
         x = self.extract_feat(img)[0]
         if self.diffusion == 'ddim':
@@ -187,24 +200,32 @@ class DDP(nn.Module, _SamplerMixin):
             out = self.ddpm_sample(x, img_meta)
         else:
             raise NotImplementedError
-        crop = out_size = None
-        flip = None
-        if img_meta:
-            m = img_meta[0]
-            if rescale:
-                crop = tuple(m['img_shape'][:2])
-                out_size = tuple(m['ori_shape'][:2])
-            if m.get('flip', False):
-                flip = m.get('flip_direction', 'horizontal')
-        seg = seg_postprocess(out, img.shape[2:], crop, out_size, self.align_corners, flip)
-        return list(seg.cpu().numpy().astype('int64'))
+        b = out.shape[0]
+        if img_meta and len(img_meta) not in (1, b):
+            raise ValueError(f'{len(img_meta)} img_metas for a batch of {b} images')
+        args = [self._epilogue_args(img_meta[i if len(img_meta) == b else 0] if img_meta else None, rescale)
+                for i in range(b)]
+        if all(a == args[0] for a in args):
+            seg = seg_postprocess(out, img.shape[2:], args[0][0], args[0][1], self.align_corners, args[0][2])
+            return list(seg.cpu().numpy().astype('int64'))
+        res = []
+        for i, (crop, out_size, flip) in enumerate(args):
+            seg = seg_postprocess(out[i:i + 1].contiguous(), img.shape[2:], crop, out_size, self.align_corners, flip)
+            res.append(seg[0].cpu().numpy().astype('int64'))
+        return res
 
-    def forward(self, img, img_metas=None, return_loss=False, **kwargs):
+    def forward(self, img, img_metas=None, return_loss=False, rescale=True, **kwargs):
+        """base.py:62-110 ``forward`` / ``forward_test``: ``img`` / ``img_metas`` may be the one-element
+        augmentation lists the test pipeline produces."""
         if return_loss:
             raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
         if isinstance(img, (list, tuple)):
+            if len(img) != 1:
+                raise NotImplementedError('aug_test (multi-scale / flip ensembles) is not part of the MI355X path')
             img = img[0]
-        return self.simple_test(img, img_metas)
+            if img_metas is not None:
+                img_metas = img_metas[0]
+        return self.simple_test(img, img_metas, rescale)
 
     def forward_train(self, *a, **k):
         raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')

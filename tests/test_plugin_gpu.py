@@ -123,3 +123,52 @@ def test_bev_ddim_sample():
     out = model.ddim_sample([x.cuda()], head, noise=noise.unsqueeze(0).cuda())
     assert out.shape == g['out'].shape
     assert max_rel(out.cpu(), g['out']) < REL
+
+
+def test_segmentor_batched_harness():
+    """§8 f4: b > 1 images per call, every image with its own crop / rescale / flip; the mmseg call protocol
+    ``model([img], [[meta, ...]], return_loss=False, rescale=True)`` through ddp_amd.apis.single_gpu_test."""
+    import numpy as np
+    from ddp_amd import apis
+    cfg, sd, x, _, _, _ = load_case('seg_ade_k3')
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    H, W = cfg['h'] * 4, cfg['w'] * 4
+    xb = torch.cat([x, x.flip(dims=(3,))]).cuda()
+    model.backbone = FakeBackbone(xb)
+    img = torch.zeros(2, 3, H, W, device='cuda')
+    m0 = dict(img_shape=(H, W, 3), ori_shape=(H + 5, W + 3, 3), flip=False)
+    m1 = dict(img_shape=(H - 2, W - 4, 3), ori_shape=(H - 7, W + 9, 3), flip=True, flip_direction='horizontal')
+
+    def run(metas):
+        torch.manual_seed(3)
+        return model.simple_test(img, metas, rescale=True)
+
+    mixed, a, b = run([m0, m1]), run([m0, m0]), run([m1, m1])
+    assert mixed[0].shape == (H + 5, W + 3) and mixed[1].shape == (H - 7, W + 9)
+    assert np.array_equal(mixed[0], a[0]) and np.array_equal(mixed[1], b[1])
+    torch.manual_seed(3)
+    fwd = model([img], [[m0, m1]], return_loss=False, rescale=True)
+    assert all(np.array_equal(p, q) for p, q in zip(fwd, mixed))
+    with pytest.raises(ValueError):
+        model.simple_test(img, [m0, m1, m0])
+    with pytest.raises(NotImplementedError):
+        model([img, img], [[m0, m1], [m0, m1]], return_loss=False)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return i
+
+        def pre_eval(self, preds, indices):
+            return [(int(i), p.shape) for p, i in zip(preds, indices)]
+
+    def collate(idx):
+        return dict(img=[torch.zeros(len(idx), 3, H, W)], img_metas=[[m0 if i % 2 == 0 else m1 for i in idx]])
+
+    loader = torch.utils.data.DataLoader(DS(), batch_size=2, shuffle=False, collate_fn=collate)
+    res = apis.single_gpu_test(model, loader, pre_eval=True)
+    assert res == [(0, (H + 5, W + 3)), (1, (H - 7, W + 9)), (2, (H + 5, W + 3)), (3, (H - 7, W + 9))]
