@@ -260,6 +260,24 @@ def main():
                           f'torch CPU fp32 oracle, {tcpu:.1f} s')
         parity = {'max_rel_vs_oracle': worst, 'argmax_agreement': agree, 'images_checked': n_img,
                   'pixels_above_1e-4': bad_px, 'gate': 1e-3}
+        # The K-step output feeds argmax back into the next step, so ONE near-tie pixel that rounds the other way moves
+        # a ~20x20 neighbourhood by 1e-4..1e-3 (SURVEY.md §7 hard part 1) in any fp32 implementation.  The feedback-free
+        # figure: single-step logits (K=1, no accumulation) of image 0 against an fp64 evaluation of the oracle, beside
+        # the fp32 oracle's own distance to it, and the number of near-tie pixels of that step.
+        try:
+            eng1 = DDPEngine(sd, task, **dict(kw, batch=1, timesteps=1, accumulation=False))
+            g1 = eng1.sample(dx[:1].contiguous(), dn[:1].contiguous()).cpu().double()
+            r32 = O.ddim_sample_seg(x[:1], noise[0], sd, timesteps=1, randsteps=wl['randsteps'], bit_scale=wl['bit_scale'],
+                                    accumulation=False)
+            r64 = O.ddim_sample_seg(x[:1].double(), noise[0].double(), {k: v.double() for k, v in sd.items()}, timesteps=1,
+                                    randsteps=wl['randsteps'], bit_scale=wl['bit_scale'], accumulation=False)
+            top = r64.topk(2, dim=1).values
+            parity['single_step_logits_vs_fp64'] = {
+                'gpu_rms': float((g1 - r64).pow(2).mean().sqrt()), 'gpu_max': float((g1 - r64).abs().max()),
+                'cpu_fp32_rms': float((r32.double() - r64).pow(2).mean().sqrt()), 'cpu_fp32_max': float((r32.double() - r64).abs().max()),
+                'logit_scale': float(r64.abs().max()), 'near_tie_pixels_gap_below_1e-4': int(((top[:, 0] - top[:, 1]) < 1e-4).sum())}
+        except Exception as e:                                       # reported, never fatal for the bench line
+            parity['single_step_logits_vs_fp64'] = {'error': str(e)[:200]}
 
     if rank == 0:
         line = {

@@ -89,6 +89,8 @@ struct Layout {
   size_t vpad_floats;
   unsigned char* wstream[DDP_MAX_LAYERS];               // layer kernel: weight stream (stage images) per layer
   float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
+  unsigned char* pro_stream;                            // step prologue: W_m (8 wide) + layer 0's value / sampling proj (12 tall)
+  float* pro_bias;                                      //                layer 0's value_proj bias at [1024, 1280)
   unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
   float* tail_bias;                                     //           conv_seg bias, zero padded
   size_t total;
@@ -238,6 +240,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->vpad = cv.take(o->vpad_floats);
     o->tail_stream = reinterpret_cast<unsigned char*>(cv.take(size_t(8) * 48 * 1024 / sizeof(float)));
     o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
+    o->pro_stream = reinterpret_cast<unsigned char*>(cv.take(b3_prologue_stream_bytes() / sizeof(float)));
+    o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
     o->q_sb = takesb(o->M, 256);
     o->q1_sb = takesb(o->M, 256);
     o->s_sb = takesb(o->M, 256);
@@ -254,6 +258,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->vpad_floats = 0;
     o->tail_stream = nullptr;
     o->tail_bias = nullptr;
+    o->pro_stream = nullptr;
+    o->pro_bias = nullptr;
   }
   o->total = cv.off * sizeof(float);
 }
@@ -374,6 +380,17 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
         return DDP_E_LAUNCH;
       }
     }
+    if (c->task != DDP_TASK_DEPTH) {    // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 4 tall]
+      DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.pro_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_v[0].p, o.wp_v[0].comp_stride, 256, 256, 1, 4, 2, 8, 0, 1, 2, o.pro_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 1, 2, 2, 16, 0, 1, 2, o.pro_stream, st));
+      if (hipMemsetAsync(o.pro_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          hipMemcpyAsync(o.pro_bias + DDP_FFN, w->layers[0].value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+              hipSuccess) {
+        set_error("prologue bias copy failed");
+        return DDP_E_LAUNCH;
+      }
+    }
     // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
     if (hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
       set_error("hipMemsetAsync(vpad) failed");
@@ -413,7 +430,7 @@ int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
 }
 
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
-int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st) {
+int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st, bool l0_projected = false) {
   const int M = int(o.M);
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
@@ -421,12 +438,14 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
     const bool fused = b3_layer_fused_enabled();
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
-      if (l == 0 || !fused) {       // later layers: emitted by the previous layer kernel
+      // later layers: emitted by the previous layer kernel; layer 0: by the step prologue kernel when that ran
+      const bool own_proj = !fused || (l == 0 && !l0_projected);
+      if (own_proj) {
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
         DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
       }
-      // layer 0's value map comes from the row-major GEMM; later ones are written zero-padded by the layer kernel
-      if (l == 0 || !fused) DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
+      // a row-major GEMM leaves a plain value map; the layer / prologue kernels write it zero-padded
+      if (own_proj) DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
       else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
       const float* a = aff + size_t(l) * 512;
       if (fused) {
@@ -603,6 +622,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // "tail" mode of the layer kernel, which leaves m_{t_next} as the SB operand of the next step's concat-conv
   const bool seg_tail = o.b3 && b3_layer_fused_enabled() && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
                         o.h == o.hh && o.w == o.wh;
+  // tasks whose concat-conv feeds the encoder directly (seg): the head of the step is one kernel with layer 0's projections
+  const bool pro_fused = o.b3 && b3_layer_fused_enabled() && b3_prologue_enabled() && cfg->task == DDP_TASK_SEG && o.h == o.hh &&
+                         o.w == o.wh;
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
@@ -621,6 +643,23 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
                                 256, 0, st));
         DDP_TRY(launch_bev_resample(o.feat0, o.s, o.R, geom, st));
         DDP_TRY(publish_q(o, o.s, st));
+      } else if (o.b3 && pro_fused) {
+        // q = W_m m_t + xproj -> SB, layer 0's value / sampling projections: one persistent kernel
+        PrologueLaunch pl;
+        pl.mask_sb = o.in_sb;
+        pl.Q = o.q_sb;
+        pl.stream = o.pro_stream;
+        pl.bias_ext = o.pro_bias;
+        pl.res = o.xproj;
+        pl.res_rn = o.r > 1 ? o.r * o.N : 0;
+        pl.M = M0;
+        pl.v_out = o.vpad;
+        pl.samp_out = o.samp;
+        pl.py = o.py[0];
+        pl.px = o.px[0];
+        pl.n_tok = o.Nh;
+        pl.w = o.wh;
+        DDP_TRY(launch_b3_prologue(pl, st));
       } else if (o.b3) {
         DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, nullptr, M0, 256, 256, 0, st,
                                     TAG_FEAT));
@@ -629,7 +668,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
                                   st));
       }
     }
-    DDP_TRY(encoder_forward(weights, o, aff, st));
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused));
     if (seg_tail) {
       TailLaunch tl;
       tl.Q = o.q_sb;

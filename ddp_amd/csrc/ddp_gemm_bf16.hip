@@ -170,6 +170,7 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
 int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   if (a.M <= 0) return DDP_OK;
   b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
   la.S = a.S;
   la.Q = a.Q;
   la.stream = a.stream;
@@ -252,6 +253,41 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   }
 }
 
+int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st) {
+  if (a.M <= 0) return DDP_OK;
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  la.S = a.mask_sb;
+  la.Q = a.Q;
+  la.stream = a.stream;
+  la.bias_ext = a.bias_ext;
+  la.res = a.res;
+  la.res_rn = a.res_rn;
+  la.M = a.M;
+  la.has_next = 1;
+  la.v_out = a.v_out;
+  la.samp_out = a.samp_out;
+  la.py = a.py;
+  la.px = a.px;
+  la.n_tok = a.n_tok;
+  la.w = a.w;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_FEAT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(b3::LYR_LDS_B));
+  }
+  const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  prof_begin(TAG_FEAT, st);
+  hipLaunchKernelGGL((b3::k_layer<TAG_FEAT, 2>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  prof_end(TAG_FEAT, st);
+  return check_launch("b3::k_layer (step prologue)");
+}
+
+size_t b3_prologue_stream_bytes() { return size_t(b3::LYR_ST_OUT + b3::LYR_ST_NEXT) * b3::LYR_STAGE_B; }
 size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }
 int b3_layer_bias_floats() { return b3::LYR_BIAS_N; }
 
@@ -259,6 +295,16 @@ bool b3_layer_fused_enabled() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DDP_LAYER_FUSED");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
+
+bool b3_prologue_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DDP_PROLOGUE_FUSED");
     v = e ? atoi(e) : 1;
   }
   return v != 0;

@@ -85,9 +85,26 @@ struct TailLaunch {
   float alpha, sigma, alpha_next, sigma_next;
 };
 int launch_b3_tail(const TailLaunch& a, hipStream_t st);
+// head of a step on the same machinery: q = W_m . m_t + xproj -> SB, then layer 0's value / sampling projections
+struct PrologueLaunch {
+  const unsigned short* mask_sb;   // SB noisy map (A operand)
+  unsigned short* Q;               // SB q out
+  const unsigned char* stream;     // 8 wide stages of W_m + 8 + 4 tall stages of layer 0's value_proj / sampling projection
+  const float* bias_ext;           // zeros | value_proj bias at [1024, 1280) | zeros
+  const float* res;                // xproj rows (W_x x + b)
+  int res_rn;                      // r * N when r noisy maps share one x row block, else 0
+  int M;
+  float* v_out;                    // zero-padded value map
+  float* samp_out;
+  const float *py, *px;
+  int n_tok, w;
+};
+int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
+size_t b3_prologue_stream_bytes();
 size_t b3_layer_stream_bytes();
 int b3_layer_bias_floats();
 bool b3_layer_fused_enabled();
+bool b3_prologue_enabled();
 // W fp32 (rows, ld) -> Wp[3][rows][K]
 int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);
 // fp32 row-major (rows, C) ld -> SB

@@ -79,6 +79,9 @@ struct LayerArgs {
   unsigned short* mask_sb;       // SB noisy map m_t (256 ch): read, replaced by m_{t_next}
   int num_classes, ldl, prob_mode;   // prob_mode: 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = scores
   float alpha, sigma, alpha_next, sigma_next;
+  // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
+  const float* res;              // fp32 rows of 256 (the loop-invariant half of the concat-conv, bias included)
+  int res_rn;                    // row(m) = res_rn ? (m / res_rn) * n_tok + m % n_tok : m   (r noisy maps share one x)
 };
 
 // vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
@@ -179,6 +182,9 @@ __device__ __forceinline__ void stream_piece(unsigned long long base, unsigned v
 //         then - per token, in registers - argmax, softmax accumulation, x0 = LUT[argmax], DDIM update of the noisy
 //         map (read and written as SB: the next step's concat-conv operand).  Replaces conv_seg GEMM + k_seg_update +
 //         k_row_to_sb (segmentors/ddp.py:235-245; decode_head.py:133).
+// MODE 2: the head of a step: q = W_m . m_t + (W_x x + b) (the noisy-map half of the concat-conv, ddp.py:223-224;
+//         8 wide stages + the loop-invariant fp32 rows), q -> SB, then layer 0's value / sampling projections from the
+//         q fragments still in registers (P3).  Replaces the FEAT / VALUE / SAMP GEMM launches of every step.
 template <int TAG, int MODE = 0, int NCH = 0>
 __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
@@ -194,7 +200,7 @@ k_layer(LayerArgs la) {
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
   const unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const int n_stages = MODE == 1 ? 2 * NCH : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
+  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
   unsigned mb = 0;                                             // ring-slot LDS base (+ this wave's share)
@@ -456,8 +462,8 @@ k_layer(LayerArgs la) {
         }
       }
     }
-    if constexpr (MODE == 0) {
-    // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead)
+    if constexpr (MODE == 0 || MODE == 2) {
+    // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -467,7 +473,8 @@ k_layer(LayerArgs la) {
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == 0) b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
       }
@@ -516,6 +523,36 @@ k_layer(LayerArgs la) {
       slot = nxt(slot);
     };
     for (int st = 0; st < 6; ++st) p0_stage(st);
+    if constexpr (MODE == 2) {
+      // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
+      f32x4 xr[8][4];
+      {
+        int m = m_base + j;
+        m = m < M ? m : M - 1;
+        const size_t row = la.res_rn ? size_t(m / la.res_rn) * la.n_tok + m % la.n_tok : size_t(m);
+        const float* rp = la.res + row * 256 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) xr[t][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
+      }
+      p0_stage(6);
+      p0_stage(7);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int b = 2 * t + gp;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e] + xr[t][2 * gp + (e >> 2)][e & 3];
+          split8(xv, xa[b][0], xa[b][1], xa[b][2]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+        }
+      }
+    }
+    if constexpr (MODE == 0) {
     // residual fragments: fetched under the last two stages
     u32x4 qa[16][3];
 #pragma unroll
@@ -706,8 +743,9 @@ k_layer(LayerArgs la) {
       }
     }
 
+    }   // MODE == 0
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
-    if (la.has_next) {
+    if (MODE == 2 || la.has_next) {
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;
