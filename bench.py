@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# the pool's host driver only supports dmabuf IPC (RCCL across processes needs it); exported on the boxes already
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
