@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2, help='images timed on the CPU oracle (bounded sample)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the process-group code path (RCCL init, weight broadcast, barrier, MAX all_reduce) even at world size 1')
     ap.add_argument('--next-rows', action='store_true',
                     help='also time the rows either side of the loop on the same batch (SURVEY.md §8 f1/f2): FPN + '
                          'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
@@ -98,7 +100,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
