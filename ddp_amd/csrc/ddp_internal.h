@@ -56,7 +56,6 @@ int launch_b3_linear_res_ln(const unsigned short* A_sb, const SplitW& w, const f
                             unsigned short* out_sb, int M, int K, hipStream_t st, int tag);
 int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const float* py, const float* px, int n_tok,
                           int w, float* out, int M, hipStream_t st);
-// whole FFN block (fc1 + GELU + fc2 + residual + LayerNorm + FiLM) in one kernel (ffn_bf16x3.h)
 // layer kernel (layer_bf16x3.h): weight stream builder + launcher
 int launch_build_stages(const unsigned short* Wp, size_t comp_stride, int K, int rows_valid, int tall, int n_rowblk, int n_kblk,
                         int base, int a, int b, int c, unsigned char* stream, hipStream_t st);
