@@ -89,7 +89,7 @@ struct Layout {
   size_t vpad_floats;
   unsigned char* wstream[DDP_MAX_LAYERS];               // layer kernel: weight stream (stage images) per layer
   float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
-  unsigned char* pro_stream;                            // step prologue: W_m (8 wide) + layer 0's value / sampling proj (12 tall)
+  unsigned char* pro_stream;                            // step prologue: W_m (8 wide) + layer 0's value / sampling proj (11 tall)
   float* pro_bias;                                      //                layer 0's value_proj bias at [1024, 1280)
   unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
   float* tail_bias;                                     //           conv_seg bias, zero padded
@@ -380,10 +380,11 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
         return DDP_E_LAUNCH;
       }
     }
-    if (c->task != DDP_TASK_DEPTH) {    // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 4 tall]
+    if (c->task != DDP_TASK_DEPTH) {    // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 2 tall + 1 split-K]
       DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.pro_stream, st));
       DDP_TRY(launch_build_stages(o.wp_v[0].p, o.wp_v[0].comp_stride, 256, 256, 1, 4, 2, 8, 0, 1, 2, o.pro_stream, st));
-      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 1, 2, 2, 16, 0, 1, 2, o.pro_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 1, 1, 2, 16, 0, 1, 2, o.pro_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 2, 1, 1, 18, 64, 0, 0, o.pro_stream, st));
       if (hipMemsetAsync(o.pro_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
           hipMemcpyAsync(o.pro_bias + DDP_FFN, w->layers[0].value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
               hipSuccess) {
@@ -396,7 +397,7 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       set_error("hipMemsetAsync(vpad) failed");
       return DDP_E_LAUNCH;
     }
-    // layer-kernel weight streams: [Wo: 8 wide stages][16 x (fc1 tall, tall, fc2 wide, wide)][next Wv: 8 tall][next Wcat: 4 tall]
+    // layer-kernel weight streams: [Wo: 8 wide stages][16 x (fc1 tall, tall, fc2 wide, wide)][next Wv: 8 tall][next Wcat: 2 tall + 1 split-K]
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
       unsigned char* sp = o.wstream[l];
@@ -411,7 +412,8 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       if (l + 1 < o.L) {
         const ddp_layer_weights& nw = w->layers[l + 1];
         DDP_TRY(launch_build_stages(o.wp_v[l + 1].p, o.wp_v[l + 1].comp_stride, 256, 256, 1, 4, 2, 72, 0, 1, 2, sp, st));
-        DDP_TRY(launch_build_stages(o.wp_cat[l + 1].p, o.wp_cat[l + 1].comp_stride, 256, 96, 1, 2, 2, 80, 0, 1, 2, sp, st));
+        DDP_TRY(launch_build_stages(o.wp_cat[l + 1].p, o.wp_cat[l + 1].comp_stride, 256, 96, 1, 1, 2, 80, 0, 1, 2, sp, st));
+        DDP_TRY(launch_build_stages(o.wp_cat[l + 1].p, o.wp_cat[l + 1].comp_stride, 256, 96, 2, 1, 1, 82, 64, 0, 0, sp, st));
         if (hipMemcpyAsync(o.bias_ext[l] + DDP_FFN, nw.value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
             hipSuccess) {
           set_error("bias table copy failed");

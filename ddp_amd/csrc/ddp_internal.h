@@ -88,7 +88,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st);
 struct PrologueLaunch {
   const unsigned short* mask_sb;   // SB noisy map (A operand)
   unsigned short* Q;               // SB q out
-  const unsigned char* stream;     // 8 wide stages of W_m + 8 + 4 tall stages of layer 0's value_proj / sampling projection
+  const unsigned char* stream;     // 8 wide stages of W_m + 8 + 3 tall stages of layer 0's value_proj / sampling projection
   const float* bias_ext;           // zeros | value_proj bias at [1024, 1280) | zeros
   const float* res;                // xproj rows (W_x x + b)
   int res_rn;                      // r * N when r noisy maps share one x row block, else 0

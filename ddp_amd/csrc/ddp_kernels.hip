@@ -96,7 +96,8 @@ __global__ void k_split_weights(const float* __restrict__ W, int ld, int rows, i
 // split weight matrix, byte-for-byte what the LDS ring slot holds ([piece 3][row][16-B slot], slots XOR-swizzled).
 //   tall = 1: 64 rows x 128 k, 16 slots per row, slot = chunk ^ (row & 15)
 //   tall = 0: 256 rows x 32 k,  4 slots per row, slot = chunk ^ ((row >> 2) & 3)
-// image index = base + rowblk*c + (kblk>>1)*a + (kblk&1)*b; rows >= rows_valid are zero.
+//   tall = 2: "split-K" tall image of 32 outputs x 256 k: image row r holds output a + (r & 31), k half r >> 5
+// image index = base + rowblk*c + (kblk>>1)*a + (kblk&1)*b (tall = 2: base); rows >= rows_valid are zero.
 __global__ void __launch_bounds__(256) k_build_stages(const unsigned short* __restrict__ Wp, size_t comp_stride, int K,
                                                        int rows_valid, int tall, int n_kblk, int base, int a, int b, int c,
                                                        unsigned char* __restrict__ stream) {
@@ -105,17 +106,19 @@ __global__ void __launch_bounds__(256) k_build_stages(const unsigned short* __re
   const int idx = blockIdx.x * 256 + threadIdx.x;   // 16-B chunk of the image: 3072 per stage
   if (idx >= 3072) return;
   const int comp = idx >> 10, rem = idx & 1023;
-  int row, chunk, slot, rows_per, k_per;
+  int row, chunk, slot, grow, kcol;
   if (tall) {
-    row = rem >> 4; chunk = rem & 15; slot = chunk ^ (row & 15); rows_per = 64; k_per = 128;
+    row = rem >> 4; chunk = rem & 15; slot = chunk ^ (row & 15);
+    grow = tall == 2 ? a + (row & 31) : rowblk * 64 + row;
+    kcol = (tall == 2 ? (row >> 5) : kblk) * 128 + 8 * chunk;
   } else {
-    row = rem >> 2; chunk = rem & 3; slot = chunk ^ ((row >> 2) & 3); rows_per = 256; k_per = 32;
+    row = rem >> 2; chunk = rem & 3; slot = chunk ^ ((row >> 2) & 3);
+    grow = rowblk * 256 + row;
+    kcol = kblk * 32 + 8 * chunk;
   }
-  const int grow = rowblk * rows_per + row;
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (grow < rows_valid)
-    v = *reinterpret_cast<const uint4*>(Wp + size_t(comp) * comp_stride + size_t(grow) * K + kblk * k_per + 8 * chunk);
-  const int image = base + rowblk * c + (kblk >> 1) * a + (kblk & 1) * b;
+  if (grow < rows_valid) v = *reinterpret_cast<const uint4*>(Wp + size_t(comp) * comp_stride + size_t(grow) * K + kcol);
+  const int image = tall == 2 ? base : base + rowblk * c + (kblk >> 1) * a + (kblk & 1) * b;
   const int per_row = tall ? 16 : 4;
   *reinterpret_cast<uint4*>(stream + size_t(image) * 49152 + comp * 16384 + (row * per_row + slot) * 16) = v;
 }

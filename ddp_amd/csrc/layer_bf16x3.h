@@ -19,7 +19,7 @@
 //     GELU(fc1) feeds fc2, LayerNorm1's output feeds the next layer's projections - no LDS round trip, no shuffle;
 //   * ALL weights of the kernel are one linear STREAM of 48 KiB stage images (already in the swizzled LDS layout,
 //     built once by k_build_stages) in the order they are consumed: 8 output_proj stages, 16 x (2 fc1 + 2 fc2)
-//     stages, 8 + 4 stages of the next layer's projections.  A 3-slot LDS ring runs two stages ahead by LDS-DMA;
+//     stages, 8 + 3 stages of the next layer's projections (the last one split-K: 32 outputs x 256 k).  A 3-slot LDS ring runs two stages ahead by LDS-DMA;
 //     every piece is "1 KiB from stream + off to ring + off", so four pieces share one M0 / one base (the
 //     instruction's immediate offset moves BOTH sides - scripts/ubench/lds_dma_off.hip) and the stream simply wraps
 //     to the next token tile: the ring never drains between tiles (persistent blocks).
@@ -52,7 +52,7 @@ constexpr int LYR_BIAS_N = 1024 + 256 + 128;                  // fc1 bias | next
 constexpr int LYR_T_BO = LYR_BIAS_N, LYR_T_GA0 = LYR_T_BO + 256, LYR_T_BE0 = LYR_T_GA0 + 256, LYR_T_B2 = LYR_T_BE0 + 256,
               LYR_T_GA1 = LYR_T_B2 + 256, LYR_T_BE1 = LYR_T_GA1 + 256, LYR_TABLE_N = LYR_T_BE1 + 256;
 constexpr size_t LYR_LDS_B = size_t(LYR_BIAS_OFF) + LYR_TABLE_N * 4;
-constexpr int LYR_ST_OUT = 8, LYR_ST_FFN = 64, LYR_ST_NEXT = 12;
+constexpr int LYR_ST_OUT = 8, LYR_ST_FFN = 64, LYR_ST_NEXT = 11;   // next: 8 value_proj + 2 + 1 (split-K) sampling stages
 constexpr int LYR_STAGES = LYR_ST_OUT + LYR_ST_FFN + LYR_ST_NEXT;
 
 struct LayerArgs {
@@ -253,19 +253,20 @@ k_layer(LayerArgs la) {
   // re-read w2 / w1 / w0 of the next block right after their last use.
 #define DDP_LYR_SB __builtin_amdgcn_sched_barrier(0);
 #define DDP_LYR_K(k) std::integral_constant<int, k>{}
-#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, F)                                                                         \
+#define DDP_LYR_BLOCK2(A0, A1, X0, X1, X2, Y0, Y1, Y2, F)                                                            \
   A0 = mma(w[0][2], X0, A0); F(DDP_LYR_K(0));  DDP_LYR_SB                                                            \
-  A1 = mma(w[1][2], X0, A1); F(DDP_LYR_K(1));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][2], Y0, A1); F(DDP_LYR_K(1));  DDP_LYR_SB                                                            \
   A0 = mma(w[0][1], X1, A0); F(DDP_LYR_K(2));  DDP_LYR_SB                                                            \
-  A1 = mma(w[1][1], X1, A1); F(DDP_LYR_K(3));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][1], Y1, A1); F(DDP_LYR_K(3));  DDP_LYR_SB                                                            \
   A0 = mma(w[0][1], X0, A0); F(DDP_LYR_K(4));  DDP_LYR_SB                                                            \
-  A1 = mma(w[1][1], X0, A1); F(DDP_LYR_K(5));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][1], Y0, A1); F(DDP_LYR_K(5));  DDP_LYR_SB                                                            \
   A0 = mma(w[0][0], X2, A0); F(DDP_LYR_K(6));  DDP_LYR_SB                                                            \
-  A1 = mma(w[1][0], X2, A1); F(DDP_LYR_K(7));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][0], Y2, A1); F(DDP_LYR_K(7));  DDP_LYR_SB                                                            \
   A0 = mma(w[0][0], X1, A0); F(DDP_LYR_K(8));  DDP_LYR_SB                                                            \
-  A1 = mma(w[1][0], X1, A1); F(DDP_LYR_K(9));  DDP_LYR_SB                                                            \
+  A1 = mma(w[1][0], Y1, A1); F(DDP_LYR_K(9));  DDP_LYR_SB                                                            \
   A0 = mma(w[0][0], X0, A0); F(DDP_LYR_K(10)); DDP_LYR_SB                                                            \
-  A1 = mma(w[1][0], X0, A1); F(DDP_LYR_K(11)); DDP_LYR_SB
+  A1 = mma(w[1][0], Y0, A1); F(DDP_LYR_K(11)); DDP_LYR_SB
+#define DDP_LYR_BLOCK(A0, A1, X0, X1, X2, F) DDP_LYR_BLOCK2(A0, A1, X0, X1, X2, X0, X1, X2, F)
 
   // ---- kernel prologue: first two stages of the stream, bias table -> LDS
   int slot = 0;
@@ -294,7 +295,9 @@ k_layer(LayerArgs la) {
   f32x16 acc2[8];
   int ht = h;
 
-  // acc (+)= W[64 rows x 256 k] . xa over two "tall" stages; the ring's look-ahead is fetched on the way
+  // acc (+)= W[64 rows x 256 k] . xa over two "tall" stages; the ring's look-ahead is fetched on the way.
+  // s1 = 2: ONE "split-K" stage of 32 output rows - image rows 0..31 hold k 0..127, rows 32..63 the SAME outputs' k 128..255 -
+  // so chain a0 runs k-blocks 0..7 and chain a1 k-blocks 8..15 (the caller adds them): no zero rows are multiplied
   auto tall_stage = [&](f32x16& a0, f32x16& a1, auto s1c) __attribute__((always_inline)) {
     constexpr int s1 = decltype(s1c)::value;
     stage_begin(nxt(nxt(slot)));
@@ -306,7 +309,8 @@ k_layer(LayerArgs la) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const bool nb = b + 1 < 8;
-      const int kb = s1 * 8 + b;
+      const int kb = s1 == 2 ? b : s1 * 8 + b;
+      const int kb1 = s1 == 2 ? 8 + b : kb;
       auto fill = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if (k == 0 && nb) w[0][2] = frag1(slot, 2, 0, b + 1);
@@ -318,7 +322,7 @@ k_layer(LayerArgs la) {
         if (k == 3) dma(b, b + 1);
         if (k == 8 && b < 4) dma(8 + b, 9 + b);
       };
-      DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], fill)
+      DDP_LYR_BLOCK2(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], xa[kb1][0], xa[kb1][1], xa[kb1][2], fill)
     }
     wait_vm12();
     __syncthreads();
@@ -326,6 +330,7 @@ k_layer(LayerArgs la) {
   };
   const std::integral_constant<int, 0> I0{};
   const std::integral_constant<int, 1> I1{};
+  const std::integral_constant<int, 2> I2{};
   auto bias_init = [&](f32x16 (&a)[2], int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -773,12 +778,20 @@ k_layer(LayerArgs la) {
       for (int sc2 = 0; sc2 < 2; ++sc2) {
         f32x16 a[2];
         bias_init(a, 20 + sc2);
-        tall_stage(a[0], a[1], I0);
-        tall_stage(a[0], a[1], I1);
+        if (sc2 == 0) {
+          tall_stage(a[0], a[1], I0);
+          tall_stage(a[0], a[1], I1);
+        } else {                                               // columns 64..95 as one split-K stage: a[0] + a[1]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a[1][r] = 0.f;
+          tall_stage(a[0], a[1], I2);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a[0][r] += a[1][r];
+        }
         if (valid) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            if (sc2 == 1 && t == 1) continue;                 // columns 96..127 are padding
+            if (sc2 == 1 && t == 1) continue;                 // one 32-column tile only
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int col = sc2 * 64 + t * 32 + 8 * g + 4 * h;
@@ -787,12 +800,14 @@ k_layer(LayerArgs la) {
               if (sc2 == 0) {                                  // sampling offsets -> pixel coordinates (x, y, x, y)
                 v[0] += fj; v[1] += fi; v[2] += fj; v[3] += fi;
               } else {                                         // attention weights: softmax over the head's 4 points
+                // (hardware exp2 / rcp: 1 ulp each - the weights stay within 2e-7 of the IEEE softmax; this runs
+                // with nothing to hide behind, and expf + four IEEE divisions were 2/3 of the epilogue's instructions)
                 const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - mx);
-                const float den = v[0] + v[1] + v[2] + v[3];
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_exp2f((v[e] - mx) * 1.44269504088896340736f);
+                const float inv = __builtin_amdgcn_rcpf((v[0] + v[1]) + (v[2] + v[3]));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] /= den;
+                for (int e = 0; e < 4; ++e) v[e] *= inv;
               }
               *reinterpret_cast<f32x4*>(la.samp_out + size_t(m) * 96 + col) = v;
             }
@@ -803,6 +818,7 @@ k_layer(LayerArgs la) {
     }
   }
 #undef DDP_LYR_BLOCK
+#undef DDP_LYR_BLOCK2
 #undef DDP_LYR_K
 #undef DDP_LYR_SB
   wait_vm0();
