@@ -162,6 +162,64 @@ __device__ constexpr int GELU_SCHED[24][4] = {
     {-1, -1, -1, -1},
     {-1, -1, -1, -1}};
 
+// The same GELU + split for the eight values of a k-block that has NOTHING to hide behind (k-block 0 of every FFN chunk
+// waits for fc1's last MFMA): two values per instruction on the packed-fp32 path.  Packed fp32 shares the matrix pipe
+// (scripts/ubench/mfma_fill.hip: +19 cycles behind an MFMA), which is idle exactly here.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_split8_packed(const float (&x)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+  unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 xx = {x[2 * i], x[2 * i + 1]};
+    const f32x2 ax = {fabsf(xx[0]), fabsf(xx[1])};
+    const f32x2 a = ax * 0.84932180028801904272f;
+    f32x2 b = __builtin_elementwise_fma(a, f32x2{0.27274550239055780f, 0.27274550239055780f}, f32x2{1.0f, 1.0f});
+    f32x2 c = a * a;
+    b = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+    f32x2 p = __builtin_elementwise_fma(b, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    c = f32x2{__builtin_amdgcn_exp2f(-c[0]), __builtin_amdgcn_exp2f(-c[1])};
+    p = __builtin_elementwise_fma(p, b, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, b, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, b, f32x2{0.254829592f, 0.254829592f});
+    p = p * b;
+    p = __builtin_elementwise_fma(-p, c, f32x2{1.0f, 1.0f});              // erf(|x| / sqrt 2)
+    const f32x2 hf = xx * 0.5f, ahf = ax * 0.5f;
+    const f32x2 g = __builtin_elementwise_fma(p, ahf, hf);                // gelu(x)
+    const f32x2 gh = {__uint_as_float(__float_as_uint(g[0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(g[1]) & 0xFFFF0000u)};
+    const f32x2 r = g - gh;
+    const f32x2 rm = {__uint_as_float(__float_as_uint(r[0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(r[1]) & 0xFFFF0000u)};
+    const f32x2 r2 = r - rm;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      hh[2 * i + e] = __float_as_uint(gh[e]);
+      mm[2 * i + e] = __float_as_uint(rm[e]);
+      ll[2 * i + e] = __float_as_uint(r2[e]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p1[i] = __builtin_amdgcn_perm(hh[2 * i + 1], hh[2 * i], 0x07060302);
+    p2[i] = __builtin_amdgcn_perm(mm[2 * i + 1], mm[2 * i], 0x07060302);
+    p3[i] = __builtin_amdgcn_perm(ll[2 * i + 1], ll[2 * i], 0x07060302);
+  }
+}
+
+// split8 (gemm_bf16x3.h) with the two subtractions of each element pair as one packed instruction - for the phases of
+// the kernel that run without MFMAs
+__device__ __forceinline__ void split8_packed(const float (&x)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 g = {x[2 * i], x[2 * i + 1]};
+    const f32x2 gh = {__uint_as_float(__float_as_uint(g[0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(g[1]) & 0xFFFF0000u)};
+    const f32x2 r = g - gh;
+    const f32x2 rm = {__uint_as_float(__float_as_uint(r[0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(r[1]) & 0xFFFF0000u)};
+    const f32x2 r2 = r - rm;
+    p1[i] = __builtin_amdgcn_perm(__float_as_uint(gh[1]), __float_as_uint(gh[0]), 0x07060302);
+    p2[i] = __builtin_amdgcn_perm(__float_as_uint(rm[1]), __float_as_uint(rm[0]), 0x07060302);
+    p3[i] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302);
+  }
+}
+
 // one LDS-DMA piece of the stream: 64 lanes x 16 B, global (base + voff + IMM) -> LDS (m0base + M0ADD + 16*lane + IMM).
 // Three instructions: everything else (stage base, ring-slot base) is computed once per stage - an MFMA hides at most
 // ~5 other instructions behind it when the SIMD runs a single wave (scripts/ubench/mfma_fill.hip), so a piece must
@@ -460,7 +518,7 @@ k_layer(LayerArgs la) {
             mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
           }
           u32x4 q1, q2, q3;
-          split8(mn, q1, q2, q3);
+          split8_packed(mn, q1, q2, q3);
           *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
           *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
           *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
@@ -551,7 +609,7 @@ k_layer(LayerArgs la) {
           float xv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e] + xr[t][2 * gp + (e >> 2)][e & 3];
-          split8(xv, xa[b][0], xa[b][1], xa[b][2]);
+          split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
         }
@@ -605,7 +663,7 @@ k_layer(LayerArgs la) {
           float xv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
-          split8(xv, xa[2 * t + gp][0], xa[2 * t + gp][1], xa[2 * t + gp][2]);
+          split8_packed(xv, xa[2 * t + gp][0], xa[2 * t + gp][1], xa[2 * t + gp][2]);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -629,8 +687,8 @@ k_layer(LayerArgs la) {
       {
         float xg[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xg[e] = gelu_fast(acc1[0][e]);
-        split8(xg, hcur[0], hcur[1], hcur[2]);
+        for (int e = 0; e < 8; ++e) xg[e] = acc1[0][e];
+        gelu_split8_packed(xg, hcur[0], hcur[1], hcur[2]);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -709,22 +767,26 @@ k_layer(LayerArgs la) {
       // fresh base: otherwise the 48 64-bit addresses of the residual loads are kept (spilled) for these stores
       char* qst = qs;
       asm volatile("" : "+v"(qst));
-      float sum = 0.f;
+      // nothing to hide behind here: two channels per instruction on the packed-fp32 path
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc2[t][r];
-      const float mean = half_sum(sum) * (1.0f / 256.0f);
-      float var = 0.f;
+        for (int r = 0; r < 16; r += 2) sum2 += f32x2{acc2[t][r], acc2[t][r + 1]};
+      const float mean = half_sum(sum2[0] + sum2[1]) * (1.0f / 256.0f);
+      const f32x2 mean2 = {mean, mean};
+      f32x2 var2 = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = acc2[t][r] - mean;
-          acc2[t][r] = d;
-          var += d * d;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 d = f32x2{acc2[t][r], acc2[t][r + 1]} - mean2;
+          acc2[t][r] = d[0];
+          acc2[t][r + 1] = d[1];
+          var2 = __builtin_elementwise_fma(d, d, var2);
         }
-      const float rstd = 1.0f / sqrtf(half_sum(var) * (1.0f / 256.0f) + 1e-5f);
+      const float rstd = 1.0f / sqrtf(half_sum(var2[0] + var2[1]) * (1.0f / 256.0f) + 1e-5f);
+      const f32x2 rstd2 = {rstd, rstd};
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -733,7 +795,12 @@ k_layer(LayerArgs la) {
           const f32x4 ga = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_GA1 + ch);
           const f32x4 be = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BE1 + ch);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = acc2[t][4 * g + e] * (rstd * ga[e]) + be[e];
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 y = __builtin_elementwise_fma(f32x2{acc2[t][4 * g + e], acc2[t][4 * g + e + 1]},
+                                                     rstd2 * f32x2{ga[e], ga[e + 1]}, f32x2{be[e], be[e + 1]});
+            acc2[t][4 * g + e] = y[0];
+            acc2[t][4 * g + e + 1] = y[1];
+          }
         }
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
@@ -741,7 +808,7 @@ k_layer(LayerArgs la) {
           float xv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
-          split8(xv, xa[b][0], xa[b][1], xa[b][2]);
+          split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qst + (b * 3 + c) * 1024) = xa[b][c];
         }
