@@ -236,7 +236,9 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
       const size_t rp = (rows + 255) / 256 * 256;
       return reinterpret_cast<unsigned short*>(cv.take((rp * C * 3 + 1) / 2));
     };
-    o->vpad_floats = size_t(o->R) * (o->hh + 2) * (o->wh + 2) * 256;
+    // + one more zero row: a sample clamped to y = h reads (with weight 0) the row below the bottom border, which for the
+    // last map would otherwise be whatever follows in the workspace (0 x NaN = NaN)
+    o->vpad_floats = (size_t(o->R) * (o->hh + 2) + 1) * (o->wh + 2) * 256 + 256;
     o->vpad = cv.take(o->vpad_floats);
     o->tail_stream = reinterpret_cast<unsigned char*>(cv.take(size_t(8) * 48 * 1024 / sizeof(float)));
     o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
