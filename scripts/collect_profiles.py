@@ -61,7 +61,8 @@ if print_only:
     sys.exit(0)
 os.makedirs(dst, exist_ok=True)
 json.dump(dict(rows), open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
-for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'), ('bench.json', f'{tag}_bench.json'),
+for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),
+                  ('prof_next/**/*kernel_stats.csv', f'{tag}_kernel_stats_next_rows.csv'), ('bench.json', f'{tag}_bench.json'),
                   ('pytest_gpu.txt', f'{tag}_pytest_gpu.txt')):
     f = glob.glob(os.path.join(src, pat), recursive=True)
     if f:

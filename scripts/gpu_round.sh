@@ -15,6 +15,8 @@ REPO=$PWD
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -o ddp -- $BENCH > $REPO/$OUT/prof_run.log 2>&1
+# the rows either side of the loop (FPN, MultiStageMerging, post-loop epilogue) in their own kernel-stats pass
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_next -o ddp -- $BENCH --next-rows > $REPO/$OUT/prof_next_run.log 2>&1
 # counters in their own passes (kernel-trace only, no other trace domains); FETCH_SIZE and WRITE_SIZE do not fit
 # one pass ("exceeds the capabilities of the hardware" - rocprofv3 then hangs, hence the timeouts)
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_rd -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_rd.log 2>&1
