@@ -1,8 +1,9 @@
 """Drop-in ``DDP`` segmentor (plugin surface #1) for MMSegmentation-style configs.
 
 Keeps the constructor kwargs, attribute names, ``state_dict`` keys and the inference methods of
-segmentation/mmseg/models/segmentors/ddp.py:49-290 (``extract_feat``, ``encode_decode``,
-``ddim_sample``, ``ddpm_sample``, ``_decode_head_forward_test``, ``_get_sampling_timesteps``) while
+segmentation/mmseg/models/segmentors/ddp.py:49-290 (``extract_feat``, ``encode_decode``, ``whole_inference``,
+``inference``, ``simple_test``, ``aug_test``, ``ddim_sample``, ``ddpm_sample``, ``_decode_head_forward_test``,
+``_get_sampling_timesteps``) while
 the K-step loop itself runs in libddp_mi355x.so through ``DDPEngine``.  Unlike the reference, whose
 sampler only works for one image per call (ddp.py:219-223 allocates the noisy map with batch
 ``randsteps``), ``ddim_sample`` accepts b >= 1 images and draws independent noise for each.
@@ -176,6 +177,34 @@ class DDP(nn.Module, _SamplerMixin):
                                       align_corners=self.align_corners)
         return seg_logit
 
+    def inference(self, img, img_meta, rescale):
+        """encoder_decoder.py:251-287, mode 'whole' (what every DDP config sets): class probabilities at ``ori_shape`` with
+        the test-time flip undone - the building block of ``aug_test``.  ``simple_test`` does not go through here: its
+        fused epilogue never materialises these (B,K,H,W) tensors."""
+        cfg = self.test_cfg
+        mode = (cfg.get('mode') if isinstance(cfg, dict) else getattr(cfg, 'mode', None)) if cfg is not None else None
+        if mode not in (None, 'whole'):
+            raise NotImplementedError(f"test_cfg.mode='{mode}': only 'whole' inference is part of the MI355X path")
+        if img_meta:
+            ori_shape = img_meta[0]['ori_shape']
+            assert all(m['ori_shape'] == ori_shape for m in img_meta)
+        output = F.softmax(self.whole_inference(img, img_meta, rescale), dim=1)
+        if img_meta and img_meta[0].get('flip', False):
+            direction = img_meta[0].get('flip_direction', 'horizontal')
+            assert direction in ('horizontal', 'vertical')
+            output = output.flip(dims=(3,) if direction == 'horizontal' else (2,))
+        return output
+
+    def aug_test(self, imgs, img_metas, rescale=True):
+        """encoder_decoder.py:306-331: mean of the per-augmentation probabilities (multi-scale / flip), then argmax.
+        Every augmentation runs the full sampling loop with its own noise, as in the reference."""
+        assert rescale, 'aug_test rescales every augmentation back to ori_shape'
+        seg_logit = self.inference(imgs[0], img_metas[0], rescale)
+        for i in range(1, len(imgs)):
+            seg_logit += self.inference(imgs[i], img_metas[i], rescale)
+        seg_logit /= len(imgs)
+        return list(seg_logit.argmax(dim=1).cpu().numpy())
+
     @staticmethod
     def _epilogue_args(meta, rescale):
         crop = out_size = flip = None
@@ -221,7 +250,9 @@ class DDP(nn.Module, _SamplerMixin):
             raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
         if isinstance(img, (list, tuple)):
             if len(img) != 1:
-                raise NotImplementedError('aug_test (multi-scale / flip ensembles) is not part of the MI355X path')
+                if img_metas is None or len(img_metas) != len(img):
+                    raise ValueError(f'num of augmentations ({len(img)}) != num of image meta ({0 if img_metas is None else len(img_metas)})')
+                return self.aug_test(list(img), list(img_metas), rescale)
             img = img[0]
             if img_metas is not None:
                 img_metas = img_metas[0]

@@ -224,3 +224,41 @@ def test_neck_chain_resolves_from_the_reference_config_dict():
                              norm_cfg=dict(type='GN', num_groups=32), act_cfg=None)])
     model = ddp_amd.build_segmentor(cfg)
     assert [type(m).__name__ for m in model.neck] == ['FPN', 'MultiStageMerging']
+
+
+def test_inference_and_aug_test_post_processing():
+    """``inference`` / ``aug_test`` (encoder_decoder.py:251-331) around a stand-in ``encode_decode``: crop to img_shape,
+    resize to ori_shape, softmax, flip undone, mean over the augmentations, argmax - the host logic only (the loop
+    itself has no CPU path)."""
+    import torch.nn.functional as F
+    model = ddp_amd.build_segmentor(seg_cfg(test_cfg=dict(mode='whole'))).eval()
+    K, H, W = model.num_classes, 16, 24
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1, K, H, W, generator=g)
+
+    def fake_encode_decode(img, img_meta):            # "logits" that follow the image content: flipped input -> flipped map
+        return base.flip(dims=(3,)) if bool(img[0, 0, 0, 0] > 0) else base.clone()
+
+    model.encode_decode = fake_encode_decode
+    plain = dict(img_shape=(H - 2, W - 4, 3), ori_shape=(H + 3, W + 5, 3), flip=False)
+    flipped = dict(plain, flip=True, flip_direction='horizontal')
+    img, img_f = torch.zeros(1, 3, H, W), torch.ones(1, 3, H, W)
+
+    def expect(logits, flip):
+        x = F.interpolate(logits[:, :, :H - 2, :W - 4], size=(H + 3, W + 5), mode='bilinear', align_corners=model.align_corners)
+        x = F.softmax(x, dim=1)
+        return x.flip(dims=(3,)) if flip else x
+
+    assert torch.allclose(model.inference(img, [plain], True), expect(base, False))
+    assert torch.allclose(model.inference(img_f, [flipped], True), expect(base.flip(dims=(3,)), True))
+    assert model.inference(img, None, False).shape == (1, K, H, W)
+    got = model.aug_test([img, img_f], [[plain], [flipped]])
+    want = ((expect(base, False) + expect(base.flip(dims=(3,)), True)) / 2).argmax(1)[0].numpy()
+    assert len(got) == 1 and (got[0] == want).all()
+    # forward() dispatch: one augmentation -> simple_test (needs the GPU), several -> aug_test
+    assert (model([img, img_f], [[plain], [flipped]], return_loss=False)[0] == want).all()
+    with pytest.raises(ValueError):
+        model([img, img_f], [[plain]], return_loss=False)
+    model.test_cfg = dict(mode='slide', crop_size=(8, 8), stride=(4, 4))
+    with pytest.raises(NotImplementedError):
+        model.inference(img, [plain], True)

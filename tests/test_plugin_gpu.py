@@ -153,8 +153,13 @@ def test_segmentor_batched_harness():
     assert all(np.array_equal(p, q) for p, q in zip(fwd, mixed))
     with pytest.raises(ValueError):
         model.simple_test(img, [m0, m1, m0])
-    with pytest.raises(NotImplementedError):
-        model([img, img], [[m0, m1], [m0, m1]], return_loss=False)
+    # aug_test (encoder_decoder.py:306-331): two augmentations of the batch, the second one flipped
+    mf = dict(m0, flip=True, flip_direction='horizontal')
+    aug = model([img, img], [[m0, m0], [mf, mf]], return_loss=False)
+    assert len(aug) == 2 and all(a.shape == (H + 5, W + 3) for a in aug)
+    assert all(0 <= int(a.min()) and int(a.max()) < cfg['num_classes'] for a in aug)
+    with pytest.raises(ValueError):
+        model([img, img], [[m0, m0]], return_loss=False)
 
     class DS(torch.utils.data.Dataset):
         def __len__(self):
