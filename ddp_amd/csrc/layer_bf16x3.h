@@ -248,15 +248,20 @@ __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  // EXPERIMENT (untested on hardware): everything derived from the lane index is RE-DERIVED at the start of every phase
+  // from a fresh (opaque) lane id instead of living in registers across the whole kernel.  The values are identical -
+  // functionally a no-op - but the register allocator no longer spills them around the phases that do not need them:
+  // a scratch reload is vector memory, completes in order behind the weight-stream DMA and every earlier load, and so
+  // costs a full memory round trip of idle matrix pipe at one wave per SIMD.
+  int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31;
-  const int h = lane >> 5;
+  int j = lane & 31;
+  int h = lane >> 5;
   const int M = la.M;
   const int ntiles = (M + LYR_BM - 1) / LYR_BM;
   if (int(blockIdx.x) >= ntiles) return;
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
-  const unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
+  unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
   const int n_stages = MODE == 1 ? 2 * NCH : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
@@ -296,13 +301,26 @@ k_layer(LayerArgs la) {
 
   // fragment reads (per-lane base + slot base + compile-time offsets)
   const char* lbase = reinterpret_cast<const char*>(smem);
-  const int f1_lane = j * 256;      // "tall" stage [64 rows x 128 k]: row t*32+j, 16 slots of 16 B, swizzle (row & 15)
-  const int f2_lane = j * 64;       // "wide" stage [256 rows x 32 k]: row t*32+j, 4 slots, swizzle ((row>>2) & 3)
+  int f1_lane = j * 256;            // "tall" stage [64 rows x 128 k]: row t*32+j, 16 slots of 16 B, swizzle (row & 15)
+  int f2_lane = j * 64;             // "wide" stage [256 rows x 32 k]: row t*32+j, 4 slots, swizzle ((row>>2) & 3)
   auto frag1 = [&](int slot, int comp, int t, int b) -> u32x4 {      // K16 step b (0..7)
     return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 8192 + f1_lane + (((2 * b + h) ^ (j & 15)) << 4));
   };
   auto frag2 = [&](int slot, int comp, int t, int ks) -> u32x4 {     // K16 step ks (0..1)
     return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
+  };
+
+  auto refresh = [&]() __attribute__((always_inline)) {
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    lane = int(l);
+    j = lane & 31;
+    h = lane >> 5;
+    voff0 = unsigned(lane * 16);
+    voff1 = voff0 + 4096;
+    voff2 = voff0 + 8192;
+    f1_lane = j * 256;
+    f2_lane = j * 64;
   };
 
   // One block = 12 MFMAs on a tile pair (two independent accumulator chains, 6 split products each) with a filler
@@ -409,6 +427,7 @@ k_layer(LayerArgs la) {
       asm volatile("" : "+v"(tab_off));
       bias_s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + tab_off);
     }
+    refresh();
     ht = h;                                                    // same for the lane's table index
     asm volatile("" : "+v"(ht));
     const int m_base = tile * LYR_BM + wave * 32;
@@ -674,6 +693,7 @@ k_layer(LayerArgs la) {
       }
     }
 
+    refresh();
     // ---- P2: FFN, 64 hidden channels at a time: acc1 = b1 + W1[chunk] . x; h = GELU(acc1); acc2 += W2[:, chunk] . h
     for (int hc = 0; hc < 16; ++hc) {
       f32x16 acc1[2];
@@ -762,6 +782,7 @@ k_layer(LayerArgs la) {
       }
     }
 
+    refresh();
     // ---- LayerNorm1 x FiLM: q' -> HBM as SB, and -> registers as the B fragments of the next projections
     {
       // fresh base: otherwise the 48 64-bit addresses of the residual loads are kept (spilled) for these stores
@@ -816,6 +837,7 @@ k_layer(LayerArgs la) {
     }
 
     }   // MODE == 0
+    refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
     if (MODE == 2 || la.has_next) {
       const int m = m_base + j;
