@@ -248,9 +248,9 @@ __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
-  // EXPERIMENT (untested on hardware): everything derived from the lane index is RE-DERIVED at the start of every phase
-  // from a fresh (opaque) lane id instead of living in registers across the whole kernel.  The values are identical -
-  // functionally a no-op - but the register allocator no longer spills them around the phases that do not need them:
+  // Everything derived from the lane index is RE-DERIVED at the start of every phase (refresh()) from a fresh, opaque lane
+  // id instead of living in registers across the whole kernel.  The values are identical - functionally a no-op - but
+  // the register allocator no longer spills them around the phases that do not need them (0 B of scratch instead of 76):
   // a scratch reload is vector memory, completes in order behind the weight-stream DMA and every earlier load, and so
   // costs a full memory round trip of idle matrix pipe at one wave per SIMD.
   int lane = tid & 63;
