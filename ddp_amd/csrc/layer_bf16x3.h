@@ -785,8 +785,9 @@ k_layer(LayerArgs la) {
     refresh();
     // ---- LayerNorm1 x FiLM: q' -> HBM as SB, and -> registers as the B fragments of the next projections
     {
-      // fresh base: otherwise the 48 64-bit addresses of the residual loads are kept (spilled) for these stores
-      char* qst = qs;
+      // fresh base (re-derived, not copied: qs would have to live - spilled - across the FFN): otherwise the 48 64-bit
+      // addresses of the residual loads are kept for these stores
+      char* qst = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
       asm volatile("" : "+v"(qst));
       // nothing to hide behind here: two channels per instruction on the packed-fp32 path
       f32x2 sum2 = {0.f, 0.f};
@@ -843,13 +844,17 @@ k_layer(LayerArgs la) {
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;
-      const int bimg = mm / la.n_tok;
-      const int n = mm - bimg * la.n_tok;
-      const int pi = n / la.w;
-      const int pj = n - pi * la.w;
+      // opaque per tile: otherwise the reciprocals behind these divisions are hoisted out of the tile loop and held
+      // (spilled) across all of it
+      int ntk = la.n_tok, wmap = la.w;
+      asm volatile("" : "+s"(ntk), "+s"(wmap));
+      const int bimg = mm / ntk;
+      const int n = mm - bimg * ntk;
+      const int pi = n / wmap;
+      const int pj = n - pi * wmap;
       const float fi = float(pi), fj = float(pj);
-      const int hmap = la.n_tok / la.w;
-      const size_t vrow = size_t(bimg) * (hmap + 2) * (la.w + 2) + size_t(pi + 1) * (la.w + 2) + (pj + 1);
+      const int hmap = ntk / wmap;
+      const size_t vrow = size_t(bimg) * (hmap + 2) * (wmap + 2) + size_t(pi + 1) * (wmap + 2) + (pj + 1);
       for (int vc = 0; vc < 4; ++vc) {
         f32x16 a[2];
         bias_init(a, 16 + vc);
@@ -864,9 +869,22 @@ k_layer(LayerArgs la) {
               *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]};
         }
       }
+#pragma unroll
       for (int sc2 = 0; sc2 < 2; ++sc2) {
         f32x16 a[2];
         bias_init(a, 20 + sc2);
+        // the positional term py[i] + px[j] of this chunk's columns is fetched HERE, in front of the chunk's stages, not in
+        // its epilogue: there, "2 loads, wait, compute, store" per column group made every group wait for the store before
+        // it and for the weight-stream DMA in flight (vector memory completes in order) - a memory round trip each, at
+        // one wave per SIMD.  (Rows of clamped tokens are valid addresses; chunk 1 has one 32-column tile.)
+        f32x4 pos[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = sc2 * 64 + (sc2 == 1 ? 0 : t) * 32 + 8 * g + 4 * h;
+            pos[t][g] = *reinterpret_cast<const f32x4*>(la.py + pi * 96 + col) + *reinterpret_cast<const f32x4*>(la.px + pj * 96 + col);
+          }
         if (sc2 == 0) {
           tall_stage(a[0], a[1], I0);
           tall_stage(a[0], a[1], I1);
@@ -884,8 +902,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int col = sc2 * 64 + t * 32 + 8 * g + 4 * h;
-              const f32x4 pos = *reinterpret_cast<const f32x4*>(la.py + pi * 96 + col) + *reinterpret_cast<const f32x4*>(la.px + pj * 96 + col);
-              f32x4 v = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]} + pos;
+              f32x4 v = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]} + pos[t][g];
               if (sc2 == 0) {                                  // sampling offsets -> pixel coordinates (x, y, x, y)
                 v[0] += fj; v[1] += fi; v[2] += fj; v[3] += fi;
               } else {                                         // attention weights: softmax over the head's 4 points
