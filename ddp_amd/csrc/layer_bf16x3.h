@@ -477,6 +477,12 @@ k_layer(LayerArgs la) {
       }
       // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
       if (!valid || bi >= K) bi = 0;
+      // Every global load of the epilogue is issued in a batch ahead of its consumers.  The straightforward loops (load 5,
+      // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
+      // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores
+      // too, and the LUT loads may not move above the map stores they could alias.
+      float* pr = la.prob + size_t(valid ? m : 0) * la.ldl + 4 * h;
+      char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
       if (la.prob_mode == 1 || la.prob_mode == 2) {          // softmax over the classes, accumulated over the steps
         float ssum = 0.f;
 #pragma unroll
@@ -499,8 +505,9 @@ k_layer(LayerArgs la) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[c][t][r] = lg[c][t][r] * inv;
       }
-      if (valid && la.prob_mode != 0) {
-        float* pr = la.prob + size_t(m) * la.ldl + 4 * h;
+      const bool accumulate = la.prob_mode == 2;
+      f32x4 old[NCH > 0 ? NCH : 1][2][4];
+      if (accumulate) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -508,39 +515,64 @@ k_layer(LayerArgs la) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int cls0 = c * 64 + t * 32 + 8 * g;
-              if (cls0 + 4 * h < K) {                          // (rows are padded to ldl >= roundup(K, 32))
-                f32x4 v = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
-                f32x4* d = reinterpret_cast<f32x4*>(pr + cls0);
-                if (la.prob_mode == 2) v = v + *d;
-                *d = v;
-              }
+              // columns past the row (ldl >= roundup(K, 32)) are never used: read column 0 instead
+              old[c][t][g] = *reinterpret_cast<const f32x4*>(cls0 + 4 * h < K ? pr + cls0 : pr);
             }
       }
-      // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out
+      if (accumulate) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[c][t][r] += old[c][t][r >> 2][r & 3];
+      }
+      if (valid && la.prob_mode != 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cls0 = c * 64 + t * 32 + 8 * g;
+              if (cls0 + 4 * h < K)                            // (rows are padded to ldl >= roundup(K, 32))
+                *reinterpret_cast<f32x4*>(pr + cls0) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
+            }
+      }
+      // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out - two batches of eight K16 blocks:
+      // 24 + 16 loads in flight, then eight compute / store rounds (all 16 blocks at once need 320 architectural VGPRs)
       {
         const float* x0row = la.lut + size_t(bi) * 256 + 4 * h;
-        char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
         const float inv_sig = 1.0f / fmaxf(la.sigma, 1e-8f);
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          const u32x4 p1 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 0) * 1024);
-          const u32x4 p2 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 1) * 1024);
-          const u32x4 p3 = *reinterpret_cast<const u32x4*>(ms + (b * 3 + 2) * 1024);
-          const f32x4 xlo = *reinterpret_cast<const f32x4*>(x0row + 16 * b);
-          const f32x4 xhi = *reinterpret_cast<const f32x4*>(x0row + 16 * b + 8);
-          float mn[8];
+        for (int half = 0; half < 2; ++half) {
+          u32x4 mk[8][3];
+          f32x4 xl[8][2];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float mt = (bf_elem(p1, u) + bf_elem(p2, u)) + bf_elem(p3, u);
-            const float x0 = u < 4 ? xlo[u] : xhi[u - 4];
-            const float pn = (mt - la.alpha * x0) * inv_sig;
-            mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
+          for (int i = 0; i < 8; ++i) {
+            const int b = half * 8 + i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mk[i][c] = *reinterpret_cast<const u32x4*>(ms + (b * 3 + c) * 1024);
+            xl[i][0] = *reinterpret_cast<const f32x4*>(x0row + 16 * b);
+            xl[i][1] = *reinterpret_cast<const f32x4*>(x0row + 16 * b + 8);
           }
-          u32x4 q1, q2, q3;
-          split8_packed(mn, q1, q2, q3);
-          *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
-          *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
-          *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int b = half * 8 + i;
+            float mn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float mt = (bf_elem(mk[i][0], u) + bf_elem(mk[i][1], u)) + bf_elem(mk[i][2], u);
+              const float x0 = u < 4 ? xl[i][0][u] : xl[i][1][u - 4];
+              const float pn = (mt - la.alpha * x0) * inv_sig;
+              mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
+            }
+            u32x4 q1, q2, q3;
+            split8_packed(mn, q1, q2, q3);
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
+          }
         }
       }
     }
