@@ -81,6 +81,25 @@ def usable_cores():
     return n
 
 
+def require_devices(n):
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f'bench.py: {n} device(s) required, {have} visible (one rank per GPU; there is no CPU path)')
+
+
+def relaunch_distributed(n):
+    """`python bench.py --gpus N` (N > 1) without a rendezvous environment: re-exec under torch.distributed.run."""
+    import socket
+    import subprocess
+    require_devices(n)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,9 +116,17 @@ def main():
                          'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (the reference's tools/dist_test.sh:10-20 does the same with
+        # torch.distributed.launch --nproc_per_node=$GPUS): one rank per GPU over RCCL, rank 0 prints the JSON line
+        sys.exit(relaunch_distributed(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} '
+                         f'(or run `python bench.py --gpus {args.gpus}` without a rendezvous environment)')
+    require_devices(world)
     dist_on = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -121,6 +148,12 @@ def main():
         if rank != 0:
             weights.flat.zero_()
         weights.broadcast(src=0)
+        # every rank now holds rank 0's blob: compare checksums through the group (also exercises all_gather over RCCL)
+        chk = weights.flat.double().sum().reshape(1)
+        got = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(got, chk)
+        if not all(bool(g == got[0]) for g in got):
+            raise SystemExit(f'bench.py: weight replicas differ after the RCCL broadcast: {[float(g) for g in got]}')
     kw = dict(h=h, w=w, batch=B, randsteps=wl['randsteps'], timesteps=K, num_classes=wl['num_classes'],
               bit_scale=wl['bit_scale'], accumulation=wl['accumulation'], feat_channels=cx, device=dev, weights=weights)
     if task == 'bev':
@@ -166,7 +199,7 @@ def main():
         _lib.check(lib.ddp_profile_end(C.byref(tot), C.byref(n)))
         torch.cuda.synchronize()
         avg_ms = tot.value / max(n.value, 1)
-        if eng.gemm == 'bf16x3' and os.environ.get('DDP_LAYER_FUSED', '1') != '0':
+        if eng.gemm == 'bf16x3' and eng.fused_layer:
             # layer kernel, algorithmic fp32 flops per token: output_proj 2*256*256 + FFN 2*2*256*1024 every layer,
             # + next layer's value_proj 2*256*256 and sampling projection 2*256*96 for all but the last layer;
             # averaged over the L launches of a step
@@ -191,22 +224,35 @@ def main():
                         frac=round(achieved / peak, 4), traffic=None,
                         launches=n.value, avg_launch_ms=round(avg_ms, 4),
                         flops_per_launch=flops_launch)
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
-        # (scripts/gpu_round.sh -> scripts/collect_profiles.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE uncalibrated)
+        # HBM bytes per launch of that kernel: measured by separate rocprofv3 --pmc passes of this same command
+        # (scripts/gpu_round.sh -> scripts/collect_profiles.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE uncalibrated) and
+        # committed under profiles/.  Only a summary taken from the SAME kernel sources (sha over csrc/ + the header) is
+        # quoted; otherwise traffic stays null rather than describing another code state.
+        roofline['traffic_source'] = None
         try:
+            import glob
+            from ddp_amd import build as _b
+            cur = _b.source_hash()
+            roofline['source_sha'] = cur
             if args.workload != 'ade_swin_t_k3_8x512x1024':
                 raise KeyError('PMC passes exist for the headline workload only')
-            import glob
-            summ = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
-            key = 'k_layer' if 'k_layer' in kernel else ('k_gemm<8, ddp::b3::EpiResLNSB, 7>' if eng.gemm == 'bf16x3'
-                                                        else 'k_gemm_tok<8, true, ddp::EpiResLNBlk, 7>')
-            for name, e in json.load(open(summ)).items():
-                if key in name and 'hbm_read_bytes_per_launch' in e:
-                    roofline['traffic'] = int(e['hbm_read_bytes_per_launch'] + e.get('hbm_write_bytes_per_launch_uncalibrated', 0))
-                    roofline['traffic_source'] = os.path.basename(summ)
+            key = 'k_layer<7' if 'k_layer' in kernel else ('k_gemm<8, ddp::b3::EpiResLNSB, 7>' if eng.gemm == 'bf16x3'
+                                                          else 'k_gemm_tok<8, true, ddp::EpiResLNBlk, 7>')
+            for summ in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')), reverse=True):
+                d = json.load(open(summ))
+                if d.get('_meta', {}).get('source_sha') != cur:
+                    continue
+                for name, e in d.items():
+                    if key in name and 'hbm_read_bytes_per_launch' in e:
+                        roofline['traffic'] = int(e['hbm_read_bytes_per_launch'] + e.get('hbm_write_bytes_per_launch_uncalibrated', 0))
+                        roofline['traffic_source'] = os.path.basename(summ) + ' (same kernel sources, sha ' + cur + ')'
+                        break
+                if roofline['traffic'] is not None:
                     break
-        except Exception:
-            pass
+            if roofline['traffic'] is None:
+                roofline['traffic_source'] = 'no committed PMC summary matches these kernel sources (sha ' + cur + ')'
+        except Exception as e:
+            roofline['traffic_source'] = str(e)[:120]
         # whole-loop dense-contraction rate for context
         loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes'], cx) * float(M) * K
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
@@ -243,52 +289,72 @@ def main():
     # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ade_swin_t_k3_8x512x1024':
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ddp_oracle as O
         cores = usable_cores()
         torch.set_num_threads(cores)
-        n_img = max(1, min(args.cpu_images, B))
+        headline = args.workload == 'ade_swin_t_k3_8x512x1024'
+        n_img = max(1, min(args.cpu_images if headline else 1, B))
+        r = wl['randsteps']
+
+        def oracle_run(b, steps=K, dtype=torch.float32, accumulation=wl['accumulation']):
+            """the reference's sampler for ONE image of the batch (the reference loop is b = 1), restated on the CPU"""
+            xs, ns = x[b:b + 1].to(dtype), noise[b].to(dtype)
+            sdd = sd if dtype == torch.float32 else {k: v.to(dtype) for k, v in sd.items()}
+            if task == 'seg':
+                return O.ddim_sample_seg(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'], accumulation=accumulation)
+            if task == 'depth':
+                return O.sample_depth(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'])
+            return O.ddim_sample_bev(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'],
+                                     input_scope=tuple(map(tuple, wl['bev_input_scope'])),
+                                     output_scope=tuple(map(tuple, wl['bev_output_scope'])))
         gpu_out = out.cpu()
         tcpu = 0.0
         worst, agree, bad_px = 0.0, 1.0, 0
         for b in range(n_img):
             t1 = time.perf_counter()
-            ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=wl['randsteps'],
-                                    bit_scale=wl['bit_scale'], accumulation=wl['accumulation'])
+            ref = oracle_run(b)
             tcpu += time.perf_counter() - t1
             rel = (gpu_out[b:b + 1] - ref).abs().amax(1) / ref.abs().max()
             worst = max(worst, float(rel.max()))
             bad_px += int((rel > 1e-4).sum())
-            agree = min(agree, float((gpu_out[b:b + 1].argmax(1) == ref.argmax(1)).float().mean()))
+            if task == 'seg':
+                agree = min(agree, float((gpu_out[b:b + 1].argmax(1) == ref.argmax(1)).float().mean()))
+            elif task == 'bev':
+                agree = min(agree, float(((gpu_out[b:b + 1] > 0.5) == (ref > 0.5)).float().mean()))
         cpu = dict(value=round(n_img / tcpu, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                   sample=f'{n_img} x (1x512x1024, {K}-step DDIM, 150 classes) of the same synthetic workload, '
+                   sample=f'{n_img} x (1 image of {args.workload}: {h}x{w} map, {K}-step sampler) of the same synthetic workload, '
                           f'torch CPU fp32 oracle, {tcpu:.1f} s')
-        parity = {'max_rel_vs_oracle': worst, 'argmax_agreement': agree, 'images_checked': n_img,
-                  'pixels_above_1e-4': bad_px, 'gate': 1e-3}
+        parity = {'max_rel_vs_oracle': worst, 'images_checked': n_img, 'pixels_above_1e-4': bad_px, 'gate': 1e-3}
+        if task != 'depth':
+            parity['argmax_agreement' if task == 'seg' else 'thresholded_agreement'] = agree
         # The K-step output feeds argmax back into the next step, so ONE near-tie pixel that rounds the other way moves
         # a ~20x20 neighbourhood by 1e-4..1e-3 (SURVEY.md §7 hard part 1) in any fp32 implementation.  The feedback-free
-        # figure: single-step logits (K=1, no accumulation) of image 0 against an fp64 evaluation of the oracle, beside
-        # the fp32 oracle's own distance to it, and the number of near-tie pixels of that step.
+        # figure: single-step scores (K=1, no accumulation) of image 0 against an fp64 evaluation of the oracle, beside
+        # the fp32 oracle's own distance to it, and (seg) the number of near-tie pixels of that step.
         try:
-            eng1 = DDPEngine(sd, task, **dict(kw, batch=1, timesteps=1, accumulation=False))
+            eng1 = DDPEngine(sd, task, **dict(kw, batch=1, timesteps=1, accumulation=False, weights=weights))
             g1 = eng1.sample(dx[:1].contiguous(), dn[:1].contiguous()).cpu().double()
-            r32 = O.ddim_sample_seg(x[:1], noise[0], sd, timesteps=1, randsteps=wl['randsteps'], bit_scale=wl['bit_scale'],
-                                    accumulation=False)
-            r64 = O.ddim_sample_seg(x[:1].double(), noise[0].double(), {k: v.double() for k, v in sd.items()}, timesteps=1,
-                                    randsteps=wl['randsteps'], bit_scale=wl['bit_scale'], accumulation=False)
-            top = r64.topk(2, dim=1).values
-            parity['single_step_logits_vs_fp64'] = {
-                'gpu_rms': float((g1 - r64).pow(2).mean().sqrt()), 'gpu_max': float((g1 - r64).abs().max()),
-                'cpu_fp32_rms': float((r32.double() - r64).pow(2).mean().sqrt()), 'cpu_fp32_max': float((r32.double() - r64).abs().max()),
-                'logit_scale': float(r64.abs().max()), 'near_tie_pixels_gap_below_1e-4': int(((top[:, 0] - top[:, 1]) < 1e-4).sum())}
+            r32 = oracle_run(0, 1, torch.float32, False)
+            r64 = oracle_run(0, 1, torch.float64, False)
+            fb = {'gpu_rms': float((g1 - r64).pow(2).mean().sqrt()), 'gpu_max': float((g1 - r64).abs().max()),
+                  'cpu_fp32_rms': float((r32.double() - r64).pow(2).mean().sqrt()), 'cpu_fp32_max': float((r32.double() - r64).abs().max()),
+                  'scale': float(r64.abs().max())}
+            if task == 'seg':
+                top = r64.topk(2, dim=1).values
+                fb['near_tie_pixels_gap_below_1e-4'] = int(((top[:, 0] - top[:, 1]) < 1e-4).sum())
+            parity['single_step_vs_fp64'] = fb
         except Exception as e:                                       # reported, never fatal for the bench line
-            parity['single_step_logits_vs_fp64'] = {'error': str(e)[:200]}
+            parity['single_step_vs_fp64'] = {'error': str(e)[:200]}
 
+    # what the process group itself says (never the --gpus flag): 1 without a group
+    n_ranks = dist.get_world_size() if dist_on else 1
+    assert n_ranks == world
     if rank == 0:
         line = {
             'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node' if args.workload == 'ade_swin_t_k3_8x512x1024'
                       else f'images/s at {K} DDIM steps ({args.workload})',
-            'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': n_ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (bf16x3-split MFMA products, fp32 accumulate)' if eng.gemm == 'bf16x3' else 'f32',
@@ -299,6 +365,7 @@ def main():
                                                     f' ({task} decoder, batch {B} per GPU, x ({B},{cx},{h},{w}), random-init weights)'),
                        'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
+            'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
             'images_per_s_per_gpu': round(images_per_s / world, 3),
             'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows,
         }

@@ -10,11 +10,12 @@ from . import build as _build
 
 MAX_LAYERS = 12
 MAX_STEPS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
+FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE = 1, 2
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
 
@@ -29,7 +30,7 @@ class DdpCfg(C.Structure):
         ('threshold', C.c_float),
         ('bev_in_min', C.c_float * 2), ('bev_in_max', C.c_float * 2),
         ('bev_out_first', C.c_float * 2), ('bev_out_step', C.c_float * 2),
-        ('gemm_mode', C.c_int32),
+        ('gemm_mode', C.c_int32), ('flags', C.c_int32),
     ]
 
 
@@ -67,7 +68,7 @@ class DdpFcnConv(C.Structure):
 
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
-           'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_time_embed', 'ddp_ddim_update_seg',
+           'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
            'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end']
 
 _lib = None
@@ -101,6 +102,8 @@ def load():
     lib.ddp_head_forward.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), _fp, _fp, _fp, _fp, _fp]
     lib.ddp_msda_forward.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]
     lib.ddp_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+    lib.ddp_linear_b3_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_linear_b3.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.ddp_time_embed.argtypes = [C.POINTER(DdpWeights), C.c_int, C.POINTER(C.c_float), C.c_int, _fp, _fp, _fp, _fp]
     lib.ddp_ddim_update_seg.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.POINTER(DdpStep), _fp]
     lib.ddp_seg_postprocess.argtypes = [_fp] + [C.c_int] * 12 + [_fp, _fp]

@@ -19,6 +19,17 @@ def _hipcc():
     return 'hipcc'
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources + the C-ABI header: names the code state a profile was taken from
+    (profiles/*_pmc_summary.json carry it; bench.py only quotes PMC traffic measured on the SAME sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, s), 'rb') as f:
+            h.update(s.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

@@ -82,6 +82,7 @@ struct Layout {
   float *xproj, *mask, *pred, *feat0, *q, *q1, *v, *s, *samp, *hbuf, *logits, *prob, *snoise, *xtok;
   // bf16x3 mode: split weights and split fragment-major activations
   int b3;
+  bool fused_layer, fused_pro;   // bf16x3: persistent layer kernel / step-prologue kernel in use (cfg->flags)
   SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
       wp_f1[DDP_MAX_LAYERS];
   unsigned short *q_sb, *q1_sb, *s_sb, *h_sb, *in_sb;   // in_sb: mask / x / feat staging (row-major producers)
@@ -135,6 +136,10 @@ int validate(const ddp_cfg* c) {
   }
   if (c->task == DDP_TASK_BEV && c->num_classes > 32) {
     set_error("bev supports at most 32 classes");
+    return DDP_E_BADCFG;
+  }
+  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE)) {
+    set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
   if (c->gemm_mode != DDP_GEMM_F32_MFMA && c->gemm_mode != DDP_GEMM_BF16X3) {
@@ -210,6 +215,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->prob = cv.take(o->M * o->ldl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
   o->b3 = c->gemm_mode == DDP_GEMM_BF16X3;
+  o->fused_layer = o->b3 && !(c->flags & DDP_FLAG_UNFUSED_LAYER);
+  o->fused_pro = o->fused_layer && !(c->flags & DDP_FLAG_UNFUSED_PROLOGUE);
   if (o->b3) {
     // split weights: 3 bf16 per fp32 = 1.5 floats per element
     auto takew = [&](size_t rows, size_t K) {
@@ -439,7 +446,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
     // of an element sum to its fp32 value exactly)
-    const bool fused = b3_layer_fused_enabled();
+    const bool fused = o.fused_layer;
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
       // later layers: emitted by the previous layer kernel; layer 0: by the step prologue kernel when that ran
@@ -624,10 +631,10 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
 
   // seg + DDIM on the bf16x3 engine: conv_seg, argmax, softmax accumulation, x0 LUT and the DDIM update run as the
   // "tail" mode of the layer kernel, which leaves m_{t_next} as the SB operand of the next step's concat-conv
-  const bool seg_tail = o.b3 && b3_layer_fused_enabled() && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
+  const bool seg_tail = o.fused_layer && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
                         o.h == o.hh && o.w == o.wh;
   // tasks whose concat-conv feeds the encoder directly (seg): the head of the step is one kernel with layer 0's projections
-  const bool pro_fused = o.b3 && b3_layer_fused_enabled() && b3_prologue_enabled() && cfg->task == DDP_TASK_SEG && o.h == o.hh &&
+  const bool pro_fused = o.fused_pro && cfg->task == DDP_TASK_SEG && o.h == o.hh &&
                          o.w == o.wh;
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
@@ -868,6 +875,59 @@ int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d
   }
   return launch_linear(d_a, k, false, d_w, k, d_bias, nullptr, 0, 0, 0, d_out, n, m, n, k, gelu,
                        static_cast<hipStream_t>(stream));
+}
+
+namespace {
+struct LinB3Layout {
+  unsigned short *a_sb, *wsplit;
+  size_t bytes;
+};
+int linb3_layout(int m, int n, int k, char* base, LinB3Layout* o) {
+  if (m < 1 || n < 1 || k < 32 || k % 32 || n % 4) {
+    set_error("linear_b3: m=%d n=%d k=%d (k must be a positive multiple of 32, n of 4)", m, n, k);
+    return DDP_E_BADCFG;
+  }
+  const size_t mp = (size_t(m) + 255) / 256 * 256;
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  o->a_sb = reinterpret_cast<unsigned short*>(take(mp * k * 6));
+  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * n * k * 2));
+  o->bytes = off;
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_linear_b3_workspace(int m, int n, int k, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  LinB3Layout o;
+  DDP_TRY(linb3_layout(m, n, k, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_linear_b3(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k,
+                  void* d_workspace, void* stream) {
+  DDP_TRY(check_ptr(d_a, "a"));
+  DDP_TRY(check_ptr(d_w, "w"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  LinB3Layout o;
+  DDP_TRY(linb3_layout(m, n, k, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // operands -> exact 3-way bf16 splits (activations as SB fragments, weights K-permuted), then the tile GEMM
+  DDP_TRY(launch_row_to_sb(d_a, k, o.a_sb, m, k, st));
+  DDP_TRY(launch_split_weights(d_w, k, n, k, o.wsplit, st));
+  SplitW w;
+  w.p = o.wsplit;
+  w.comp_stride = size_t(n) * k;
+  return launch_b3_linear(o.a_sb, w, d_bias, nullptr, 0, 0, 0, d_out, n, m, n, k, st, TAG_GENERIC);
 }
 
 int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time_in_host, int s, float* d_temb,

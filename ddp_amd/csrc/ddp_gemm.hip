@@ -19,14 +19,9 @@ int launch_gemm(const GemmArgs& ga_in, const Epi& epi, hipStream_t st) {
     return DDP_E_BADCFG;
   }
   ga.n_tiles_n = (ga.N + NT * 32 - 1) / (NT * 32);
-  static size_t lds = 0;          // per instantiation
-  if (!lds) {
-    lds = gemm_lds_bytes<NT, Epi>();
-    const char* e = getenv("DDP_GEMM_LDS_KB");            // probe: inflate LDS to force 1 block per CU
-    if (e && size_t(atoi(e)) * 1024 > lds) lds = size_t(atoi(e)) * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tok<NT, A_BLK, Epi, TAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  }
+  constexpr size_t lds = gemm_lds_bytes<NT, Epi>();
+  static LdsAttrOnce attr;        // per instantiation and device
+  attr.ensure(reinterpret_cast<const void*>(&k_gemm_tok<NT, A_BLK, Epi, TAG>), int(lds));
   prof_begin(TAG, st);
   hipLaunchKernelGGL((k_gemm_tok<NT, A_BLK, Epi, TAG>), dim3(gemm_grid(ga.M, ga.n_tiles_n)), dim3(GEMM_THREADS), lds, st,
                      ga, epi, g_gemm_dbg);

@@ -21,12 +21,8 @@ int launch_b3(const b3::Args& a_in, const Epi& epi, hipStream_t st) {
   }
   ga.n_tiles_n = (ga.N + NT * 32 - 1) / (NT * 32);
   constexpr size_t lds = b3::lds_bytes<NT, Epi>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_gemm<NT, Epi, TAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_gemm<NT, Epi, TAG>), int(lds));
   prof_begin(TAG, st);
   hipLaunchKernelGGL((b3::k_gemm<NT, Epi, TAG>), dim3(b3::grid(ga.M, ga.n_tiles_n)), dim3(b3::THREADS), lds, st, ga, epi);
   prof_end(TAG, st);
@@ -92,12 +88,8 @@ int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* 
   ga.conv_dil = dilation;
   ga.n_tiles_n = 1;
   constexpr size_t lds = b3::lds_bytes<8, EpiRow>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_gemm<8, EpiRow, TAG_GENERIC, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_gemm<8, EpiRow, TAG_GENERIC, true>), int(lds));
   if (ga.M <= 0) return DDP_OK;
   hipLaunchKernelGGL((b3::k_gemm<8, EpiRow, TAG_GENERIC, true>), dim3(b3::grid(ga.M, 1)), dim3(b3::THREADS), lds, st, ga, e);
   return check_launch("b3::k_gemm (conv3x3)");
@@ -189,14 +181,9 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   la.px = a.px;
   la.n_tok = a.n_tok;
   la.w = a.w;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              int(b3::LYR_LDS_B));
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN>), int(b3::LYR_LDS_B));
+  const int n_cu = cu_count();
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;       // persistent: one block per CU walks tiles blockIdx, +grid, ...
   prof_begin(TAG_FC2_LN, st);
@@ -207,12 +194,8 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
 namespace {
 template <int NCH>
 int launch_tail_t(const b3::LayerArgs& la, int grid, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, 1, NCH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(b3::LYR_LDS_B));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, 1, NCH>), int(b3::LYR_LDS_B));
   prof_begin(TAG_HEAD, st);
   hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, 1, NCH>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
   prof_end(TAG_HEAD, st);
@@ -238,9 +221,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   la.sigma = a.sigma;
   la.alpha_next = a.alpha_next;
   la.sigma_next = a.sigma_next;
-  int n_cu = 0, dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  const int n_cu = cu_count();
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;
   const int nch = (a.num_classes + 63) / 64;
@@ -271,14 +252,9 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st) {
   la.px = a.px;
   la.n_tok = a.n_tok;
   la.w = a.w;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&b3::k_layer<TAG_FEAT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              int(b3::LYR_LDS_B));
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FEAT, 2>), int(b3::LYR_LDS_B));
+  const int n_cu = cu_count();
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;
   prof_begin(TAG_FEAT, st);
@@ -290,24 +266,5 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st) {
 size_t b3_prologue_stream_bytes() { return size_t(b3::LYR_ST_OUT + b3::LYR_ST_NEXT) * b3::LYR_STAGE_B; }
 size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }
 int b3_layer_bias_floats() { return b3::LYR_BIAS_N; }
-
-bool b3_layer_fused_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DDP_LAYER_FUSED");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
-
-
-bool b3_prologue_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DDP_PROLOGUE_FUSED");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
 
 }  // namespace ddp

@@ -9,6 +9,30 @@ namespace ddp {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Per-(kernel, device) one-time setup.  A process may drive several GPUs (one engine per device): the dynamic-LDS
+// attribute has to be set on each of them, and the CU count is a property of the device the launch goes to - neither
+// may be cached process-wide.  The bit mask is idempotent state (a race only repeats the call).
+struct LdsAttrOnce {
+  unsigned long long done = 0;                       // bit per device id < 64
+  void ensure(const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  }
+};
+inline int cu_count() {                              // compute units of the CURRENT device (persistent-kernel grids)
+  static int cache[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < 64) cache[dev] = n;
+  return n;
+}
+
 // call-site tags of the GEMM launches (distinct kernel symbols for rocprofv3; profiler hook ids)
 enum GemmTag {
   TAG_GENERIC = 0, TAG_XPROJ = 1, TAG_FEAT = 2, TAG_VALUE = 3, TAG_SAMP = 4, TAG_OUTPROJ_LN = 5, TAG_FC1 = 6,
@@ -102,8 +126,6 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
 size_t b3_prologue_stream_bytes();
 size_t b3_layer_stream_bytes();
 int b3_layer_bias_floats();
-bool b3_layer_fused_enabled();
-bool b3_prologue_enabled();
 // W fp32 (rows, ld) -> Wp[3][rows][K]
 int launch_split_weights(const float* W, int ld, int rows, int K, unsigned short* out, hipStream_t st);
 // fp32 row-major (rows, C) ld -> SB

@@ -873,6 +873,9 @@ __global__ void __launch_bounds__(256) k_seg_update(SegUpdateArgs a) {
       bi = oi;
     }
   }
+  // a row without a maximum (every score NaN or -inf: a NaN in x spreads over the row through LayerNorm) must still index
+  // the LUT in range - the NaN then propagates through the update arithmetic instead of faulting (the tail kernel does the same)
+  if (bi >= K) bi = 0;
   if (a.prob && a.prob_mode) {
     float* pr = a.prob + size_t(m) * a.ldl;
     if (a.prob_mode == 3) {
@@ -1221,12 +1224,8 @@ int launch_seg_update(const SegUpdateArgs& a, hipStream_t st) {
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st) {
   const size_t lds = size_t(64) * (K + 1) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_nchw), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        64 * 257 * int(sizeof(float)));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&k_finalize_nchw), 64 * 257 * int(sizeof(float)));
   hipLaunchKernelGGL(k_finalize_nchw, dim3(cdiv(N, 64), B), dim3(256), lds, st, prob, ldl, out, r, N, K, div);
   return check_launch("k_finalize_nchw");
 }

@@ -110,7 +110,7 @@ class DDPEngine:
                  feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
-                 weights=None, gemm=None):
+                 weights=None, gemm=None, fused_layer=None, fused_prologue=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -141,6 +141,14 @@ class DDPEngine:
             cfg.head_h, cfg.head_w = (h, w) if head_hw is None else head_hw
         self.gemm = gemm if gemm is not None else default_gemm_mode()
         cfg.gemm_mode = GEMM_MODES[self.gemm]
+        # diagnostics (A/B runs, tests of the unfused kernels): DDP_LAYER_FUSED=0 / DDP_PROLOGUE_FUSED=0 or the kwargs
+        import os
+        if fused_layer is None:
+            fused_layer = os.environ.get('DDP_LAYER_FUSED', '1') != '0'
+        if fused_prologue is None:
+            fused_prologue = os.environ.get('DDP_PROLOGUE_FUSED', '1') != '0'
+        cfg.flags = (0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE)
+        self.fused_layer = bool(fused_layer)
         cfg.accumulation = int(bool(accumulation))
         cfg.bit_scale, cfg.min_depth, cfg.max_depth, cfg.threshold = bit_scale, min_depth, max_depth, threshold
         self.cfg = cfg

@@ -48,12 +48,52 @@ MODELS = Registry('models')
 BACKBONES = NECKS = HEADS = LOSSES = SEGMENTORS = DEPTHER = FUSIONMODELS = MODELS
 
 
+def _foreign_builder(kind):
+    """``build_<kind>`` of an importable MMSegmentation / depth toolbox (None when neither is installed).  The frozen
+    backbones (SwinTransformer, ConvNeXt, ...) are NOT part of ddp_amd (they stay PyTorch-ROCm modules of the
+    host toolbox), so a config that names one is resolved where the reference resolves it
+    (segmentation/mmseg/models/builder.py:18-31; depth/depth/models/builder.py)."""
+    import importlib
+    for pkg in ('mmseg.models.builder', 'depth.models.builder'):
+        try:
+            mod = importlib.import_module(pkg)
+        except ImportError:
+            continue
+        fn = getattr(mod, 'build_' + kind, None)
+        if fn is not None:
+            yield pkg, fn
+
+
+def _build_or_delegate(kind, registry, cfg):
+    """Build ``cfg`` from ddp_amd's registry when it knows the type; an already constructed ``nn.Module`` passes through;
+    any other type goes to the host toolbox's builder.  Fails loudly (KeyError naming every place that was tried)."""
+    if cfg is None:
+        return None
+    if not isinstance(cfg, dict):
+        import torch.nn as nn
+        if isinstance(cfg, nn.Module):
+            return cfg
+        raise TypeError(f'{kind} must be a config dict or an nn.Module, got {type(cfg).__name__}')
+    typ = cfg.get('type')
+    if inspect.isclass(typ) or typ in registry:
+        return registry.build(cfg)
+    tried = [f'ddp_amd.{registry.name}']
+    for pkg, fn in _foreign_builder(kind):
+        tried.append(pkg)
+        try:
+            return fn(cfg)
+        except KeyError:
+            continue
+    raise KeyError(f'{kind} type {typ!r} is not registered in any of {tried}: ddp_amd implements the DDP hot path only - '
+                   f'build the {kind} with the host toolbox (mmseg / depth) or pass a constructed nn.Module')
+
+
 def build_backbone(cfg):
-    return BACKBONES.build(cfg)
+    return _build_or_delegate('backbone', BACKBONES, cfg)
 
 
 def build_neck(cfg):
-    return NECKS.build(cfg)
+    return _build_or_delegate('neck', NECKS, cfg)
 
 
 def build_head(cfg):
@@ -87,8 +127,13 @@ def register_into_mmseg():
     from .segmentors.ddp import DDP, SelfAlignedDDP
     from .decode_heads.deformable_head_with_time import DeformableHeadWithTime
     from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime
+    # only "toolbox not installed" is tolerated: a failure half way through a registration would leave a partial
+    # drop-in behind and must surface
     try:
         from mmseg.models.builder import SEGMENTORS as MS, HEADS as MH, NECKS as MN
+    except ImportError:
+        MS = None
+    if MS is not None:
         from .necks import FPN, MultiStageMerging
         MN.register_module(name='MultiStageMerging', force=True, module=MultiStageMerging)
         MN.register_module(name='FPN', force=True, module=FPN)
@@ -98,13 +143,12 @@ def register_into_mmseg():
         from .decode_heads.fcn_head_with_time import FCNHeadWithTime
         MH.register_module(name='FCNHeadWithTime', force=True, module=FCNHeadWithTime)
         touched.append('mmseg')
-    except Exception:
-        pass
     try:
         from depth.models.builder import DEPTHER as DD, HEADS as DH
+    except ImportError:
+        DD = None
+    if DD is not None:
         DD.register_module(name='DDP', force=True, module=DepthDDP)
         DH.register_module(name='DeformableHeadWithTime', force=True, module=DepthDeformableHeadWithTime)
         touched.append('depth')
-    except Exception:
-        pass
     return touched

@@ -38,7 +38,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define DDP_ABI_VERSION 2
+#define DDP_ABI_VERSION 3
 #define DDP_MAX_LAYERS 12
 #define DDP_MAX_STEPS 64
 #define DDP_EMBED 256
@@ -58,6 +58,10 @@ enum { DDP_SAMPLER_DDIM = 0, DDP_SAMPLER_DDPM = 1 };
  *                       products run on the bf16 matrix cores with fp32 accumulation (error <= ~3 * 2^-24 per
  *                       product, i.e. fp32 round-off class), 417 TFLOP/s fp32-equivalent ceiling */
 enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
+/* ddp_cfg.flags (diagnostics, bf16x3 engine): run the decoder layer / the head of a step as the separate tile GEMMs they
+ * were fused from (identical arithmetic per contraction; used by same-box A/B runs and by the parity tests that keep
+ * the unfused kernels covered).  UNFUSED_LAYER implies the unfused step head and seg tail as well. */
+enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2 };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -81,6 +85,7 @@ typedef struct ddp_cfg {
    * input [min,max], output first centre and step: c_k = out_first + k * out_step */
   float bev_in_min[2], bev_in_max[2], bev_out_first[2], bev_out_step[2];
   int32_t gemm_mode;          /* DDP_GEMM_* */
+  int32_t flags;              /* DDP_FLAG_* (0 = the product path) */
 } ddp_cfg;
 
 typedef struct ddp_layer_weights {            /* decode_head.encoder.layers.<l>.* */
@@ -157,6 +162,15 @@ int ddp_msda_forward(const float* d_value, const float* d_samp, float* d_out, in
 /* out[M][N] = A[M][K] * W[N][K]^T + bias  (fp32 MFMA), optional exact GELU. K % 32 == 0. */
 int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k,
                int gelu, void* stream);
+
+/* The same contraction in the arithmetic of the DEFAULT engine (DDP_GEMM_BF16X3, csrc/gemm_bf16x3.h): A and W are split
+ * exactly into three bf16 pieces each and the six significant cross products run on the bf16 matrix cores with fp32
+ * accumulation.  Exposed so that the accuracy claim above is a unit test (tests/test_b3_arithmetic.py: error against
+ * fp64 <= c * 2^-24 * sum_k |a||w| on normal-range, wide-dynamic-range, cancelling and near-subnormal operands), not a
+ * comment.  out[M][N] = A[M][K] * W[N][K]^T + bias; K % 32 == 0, N % 4 == 0; d_workspace from ddp_linear_b3_workspace. */
+int ddp_linear_b3_workspace(int m, int n, int k, size_t* bytes);
+int ddp_linear_b3(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k,
+                  void* d_workspace, void* stream);
 
 /* time_mlp + per-layer FiLM on device: d_temb (S,1024), d_film (S,L,512) for S time inputs. */
 int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time_in_host, int s,

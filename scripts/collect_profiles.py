@@ -60,6 +60,12 @@ for k, e in rows[:14]:
 if print_only:
     sys.exit(0)
 os.makedirs(dst, exist_ok=True)
+out = dict(rows)
+# provenance: the hash of the kernel sources the GPU box ran (scripts/gpu_round.sh wrote it next to the counters)
+meta_f = os.path.join(src, 'source_sha.txt')
+if os.path.exists(meta_f):
+    out['_meta'] = {'source_sha': open(meta_f).read().strip(), 'tag': tag}
+rows = list(out.items())
 json.dump(dict(rows), open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),
                   ('prof_next/**/*kernel_stats.csv', f'{tag}_kernel_stats_next_rows.csv'), ('bench.json', f'{tag}_bench.json'),

@@ -7,6 +7,7 @@ TAG=${1:-rXX}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+python -c "from ddp_amd import build; print(build.source_hash())" > $OUT/source_sha.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.txt
 cat $OUT/pytest_gpu.txt
 python bench.py --steps 10 --warmup 2 --next-rows > $OUT/bench.json 2> $OUT/bench.err

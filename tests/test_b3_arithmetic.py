@@ -1,0 +1,147 @@
+"""The bf16x3 arithmetic - the thing the headline number stands on - pinned at the GEMM level.
+
+``ddp_linear_b3`` (include/ddp_mi355x.h) runs one contraction exactly the way the default engine's kernels do:
+both fp32 operands split exactly into three bf16 pieces, six cross products on the bf16 matrix cores, fp32
+accumulation (ddp_amd/csrc/gemm_bf16x3.h:1-32).  The claim under test is "fp32-class": for every output
+
+    |c - c_fp64| <= C_BOUND * 2^-24 * sum_k |a_k| |w_k|
+
+which is the bound an fp32 dot product with exact products and K fp32 additions satisfies with C ~ K/2 in the worst
+case and ~sqrt(K) typically.  The same inputs go through the exact f32-input MFMA engine (``ddp_linear``) and the
+figure is printed beside it.  Operand classes: N(0,1); wide dynamic range (2^-60 .. 2^60 mixed inside one K row);
+exactly cancelling rows; values whose THIRD piece is subnormal in bf16 (|x| ~ 2^-112 .. 2^-118: reported, and bounded
+with the absolute floor a flushed subnormal piece can cost).  Needs an MI355X: ``pytest -m gpu``.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+U = 2.0 ** -24
+C_BOUND = 8.0          # asserted multiple of 2^-24 * sum|a||w|; measured ~1 (printed)
+
+
+def _run(a, w, b, dev, engine):
+    from ddp_amd import _lib
+    lib = _lib.load()
+    m, k = a.shape
+    n = w.shape[0]
+    da, dw = a.to(dev), w.to(dev)
+    db = b.to(dev) if b is not None else None
+    out = torch.full((m, n), float('nan'), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    if engine == 'b3':
+        nbytes = C.c_size_t(0)
+        _lib.check(lib.ddp_linear_b3_workspace(m, n, k, C.byref(nbytes)))
+        ws = torch.zeros(nbytes.value // 4 + 64, dtype=torch.float32, device=dev)
+        _lib.check(lib.ddp_linear_b3(da.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, out.data_ptr(),
+                                     m, n, k, ws.data_ptr(), st))
+    else:
+        _lib.check(lib.ddp_linear(da.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, out.data_ptr(),
+                                  m, n, k, 0, st))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def _ratio(out, a, w, b):
+    ref = a.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    scale = a.double().abs() @ w.double().abs().t() + (b.double().abs() if b is not None else 0.0)
+    err = (out.double() - ref).abs()
+    return err, scale, ref
+
+
+def _pow2_mixed(shape, lo, hi, gen):
+    e = torch.randint(lo, hi + 1, shape, generator=gen).double()
+    mant = 1.0 + torch.rand(shape, generator=gen, dtype=torch.float64)
+    sign = torch.randint(0, 2, shape, generator=gen).double() * 2 - 1
+    return (sign * mant * torch.pow(torch.tensor(2.0, dtype=torch.float64), e)).float()
+
+
+@pytest.mark.parametrize('m,n,k', [(512, 256, 256), (300, 1024, 256), (257, 256, 1024), (1000, 96, 256), (77, 152, 512)])
+def test_b3_normal_operands(m, n, k):
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + 3 * n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    res = {}
+    for eng in ('b3', 'f32'):
+        out = _run(a, w, b, dev, eng)
+        assert torch.isfinite(out).all()
+        err, scale, ref = _ratio(out, a, w, b)
+        res[eng] = (float((err / (U * scale)).max()), float(err.max() / ref.abs().max()))
+    print(f'N(0,1) {m}x{n}x{k}: bf16x3 max err / (2^-24 sum|a||w|) = {res["b3"][0]:.3f} (max-rel {res["b3"][1]:.2e}); '
+          f'fp32 MFMA {res["f32"][0]:.3f} (max-rel {res["f32"][1]:.2e})')
+    assert res['b3'][0] <= C_BOUND
+    assert res['b3'][0] <= 2.0 * res['f32'][0] + 1.0          # not worse than the exact-product fp32 engine
+
+
+def test_b3_wide_dynamic_range():
+    """magnitudes 2^-60 .. 2^60 mixed inside every K row: the small terms must neither disturb nor be lost beyond
+    2^-24 of the row's sum of magnitudes"""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    m, n, k = 384, 256, 256
+    a = _pow2_mixed((m, k), -60, 60, g)
+    w = _pow2_mixed((n, k), -3, 3, g)
+    for eng in ('b3', 'f32'):
+        out = _run(a, w, None, dev, eng)
+        assert torch.isfinite(out).all()
+        err, scale, _ = _ratio(out, a, w, None)
+        r = float((err / (U * scale)).max())
+        print(f'wide range ({eng}): max err / (2^-24 sum|a||w|) = {r:.3f}')
+        if eng == 'b3':
+            assert r <= C_BOUND
+
+
+def test_b3_exact_cancellation():
+    """rows built from (+v, -v) pairs against equal weights: the exact result is the bias; every partial product
+    must cancel to within 2^-24 of the sum of magnitudes (the split is sign-symmetric, so in fact exactly)"""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(12)
+    m, n, k = 256, 256, 512
+    v = torch.randn(m, k // 2, generator=g) * 100.0
+    a = torch.stack([v, -v], -1).reshape(m, k)
+    wv = torch.randn(n, k // 2, generator=g)
+    w = torch.stack([wv, wv], -1).reshape(n, k)
+    b = torch.randn(n, generator=g) * 1e-3
+    out = _run(a, w, b, dev, 'b3')
+    err, scale, ref = _ratio(out, a, w, b)
+    r = float((err / (U * scale)).max())
+    print(f'cancelling rows: max |out - bias| = {float(err.max()):.3e}, / (2^-24 sum|a||w|) = {r:.3f}')
+    assert r <= C_BOUND
+
+
+def test_b3_tiny_operands_report():
+    """|a| ~ 2^-112 .. 2^-118: the third (and partly the second) bf16 piece of such values is subnormal in bf16.
+    If the matrix core flushes subnormal inputs, each such term loses at most its sub-2^-126 pieces: the error stays
+    below 2^-126 * |w| per term - far below anything the decoder produces (LayerNorm'd activations are O(1)) - and
+    the relative figure is reported."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(13)
+    m, n, k = 256, 256, 256
+    a = _pow2_mixed((m, k), -118, -112, g)
+    w = _pow2_mixed((n, k), -2, 2, g)
+    out = _run(a, w, None, dev, 'b3')
+    assert torch.isfinite(out).all()
+    err, scale, _ = _ratio(out, a, w, None)
+    r = float((err / (U * scale)).max())
+    floor = 2.0 ** -126 * w.double().abs().sum(1).max()          # every term's flushed pieces
+    print(f'near-subnormal operands: max err / (2^-24 sum|a||w|) = {r:.3f}; max abs err {float(err.max()):.3e}, '
+          f'flush floor {float(floor):.3e}')
+    assert bool((err <= C_BOUND * U * scale + floor).all())
+
+
+def test_b3_matches_sampler_arithmetic():
+    """transposition / layout probe (identity-like A, asymmetric W) through the split path: exact, since every operand
+    here is representable in one bf16 piece plus zeros"""
+    dev = torch.device('cuda:0')
+    m = n = k = 256
+    a = torch.eye(m, k)
+    w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) / (n * k))
+    out = _run(a, w, None, dev, 'b3')
+    assert torch.equal(out, w.t().contiguous())

@@ -1,0 +1,45 @@
+"""Drop-in proof in the reference's OWN registries (SURVEY.md §8b "drop-in boundary").
+
+Runs ``tests/dropin_probe.py`` in a subprocess (the reference import mutates sys.modules / the mmcv registries):
+``register_into_mmseg()`` + the reference's ``build_segmentor`` / ``build_depther`` on two shipped configs must resolve to
+ddp_amd's segmentor / head / neck classes, keep the reference's backbone, and expose a state_dict whose key -> shape map
+equals the reference model's (strict load both ways).  CPU only; skipped where /root/reference is absent (GPU box).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import ref_shim  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason='reference tree not present (build container only)')
+
+
+def _probe(task):
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'dropin_probe.py'), task], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_ade_config_builds_to_ddp_amd_classes_in_mmseg_registry():
+    d = _probe('seg')
+    assert d['touched'] == ['mmseg']
+    assert d['segmentor'] == 'ddp_amd.segmentors.ddp.DDP'
+    assert d['head'] == 'ddp_amd.decode_heads.deformable_head_with_time.DeformableHeadWithTime'
+    assert d['necks'] == ['FPN', 'MultiStageMerging']
+    assert d['backbone'].startswith('mmseg.models.backbones.')          # frozen backbone stays the host toolbox's
+    assert d['hot_path_params'] == 8522462                              # SURVEY.md §8b probe of the reference model
+    assert 'All keys matched' in d['strict_load']
+
+
+def test_kitti_config_builds_to_ddp_amd_classes_in_depth_registry():
+    d = _probe('depth')
+    assert d['touched'] == ['depth']
+    assert d['segmentor'] == 'ddp_amd.depther.ddp.DDP'
+    assert d['head'] == 'ddp_amd.depther.ddp.DepthDeformableHeadWithTime'
+    assert d['backbone'].startswith('depth.models.backbones.')
+    assert 'All keys matched' in d['strict_load']

@@ -156,11 +156,20 @@ def test_head_forward_trace(dev, name):
     assert max_rel(out.cpu(), g['logits_steps'][0]) < REL
 
 
+# every engine / fusion level of the library runs the reference-made fixtures: the default path (bf16x3 split products,
+# persistent layer kernel, fused step head and seg tail), the same arithmetic as separate tile GEMMs, and the exact
+# f32-input MFMA engine (include/ddp_mi355x.h DDP_GEMM_*, DDP_FLAG_*)
+VARIANTS = {'bf16x3': dict(gemm='bf16x3'), 'f32': dict(gemm='f32'),
+            'bf16x3-unfused-layer': dict(gemm='bf16x3', fused_layer=False),
+            'bf16x3-unfused-prologue': dict(gemm='bf16x3', fused_prologue=False)}
+
+
+@pytest.mark.parametrize('variant', sorted(VARIANTS))
 @pytest.mark.parametrize('name', case_names())
-def test_sample_golden(dev, name):
+def test_sample_golden(dev, name, variant):
     """the whole K-step loop vs the golden output recorded from the reference."""
     cfg, sd, x, noise, step_noise, g = load_case(name)
-    eng = _engine(cfg, sd, dev)
+    eng = _engine(cfg, sd, dev, **VARIANTS[variant])
     sn = step_noise.unsqueeze(1).contiguous().to(dev) if step_noise is not None else None
     dx, dn = x.to(dev), noise.unsqueeze(0).contiguous().to(dev)
     out = eng.sample(dx, dn, sn)
@@ -360,8 +369,9 @@ def test_fpn_then_merging_chain_matches_oracle():
 
 # ---- edge geometry: single-token maps, one layer (no "next layer" projections), the class-count limits ---------------
 @pytest.mark.gpu
+@pytest.mark.parametrize('gemm', ['bf16x3', 'f32'])
 @pytest.mark.parametrize('h,w,L,K,r', [(1, 1, 1, 2, 1), (2, 3, 2, 256, 2), (5, 4, 1, 19, 1), (3, 50, 3, 150, 1)])
-def test_sample_edge_geometry_vs_oracle(dev, h, w, L, K, r):
+def test_sample_edge_geometry_vs_oracle(dev, h, w, L, K, r, gemm):
     """maps smaller than one 32-token group / one 128-token tile, a single decoder layer, 2 and 256 classes"""
     from ddp_amd.utils import synthetic
     from oracle import ddp_oracle as O
@@ -369,7 +379,7 @@ def test_sample_edge_geometry_vs_oracle(dev, h, w, L, K, r):
     x, noise = synthetic.make_inputs(2, h, w, r, 256, 256, seed=12)
     cfg = dict(task='seg', h=h, w=w, randsteps=r, timesteps=2, bit_scale=0.01, num_classes=K, accumulation=True,
                noise_schedule='cosine', diffusion='ddim')
-    eng = _engine(cfg, sd, dev, batch=2)
+    eng = _engine(cfg, sd, dev, batch=2, gemm=gemm)
     out = eng.sample(x.to(dev), noise.to(dev)).cpu()
     for b in range(2):
         ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=2, randsteps=r, bit_scale=0.01, accumulation=True)
@@ -390,3 +400,60 @@ def test_sample_more_tiles_than_cus_ragged(dev):
     out = eng.sample(x.to(dev), noise.to(dev)).cpu()
     ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=1, randsteps=1, bit_scale=0.01, accumulation=False)
     assert max_rel(out, ref) < REL
+
+
+# ---- the exported stand-alone DDIM update, and NaN robustness of the argmax -> LUT step -----------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,ldl,rows', [(150, 160, 1000), (19, 32, 333), (256, 256, 64), (2, 32, 5)])
+def test_ddim_update_seg_entry(dev, K, ldl, rows):
+    """ddp_ddim_update_seg (x0 = LUT[argmax], DDIM step; segmentors/ddp.py:235-239) on token-major buffers vs torch"""
+    from ddp_amd import _lib, schedule
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(K * 1000 + rows)
+    logits = torch.randn(rows, ldl, generator=g)
+    logits[:, K:] = 100.0                                    # padding columns must be ignored
+    logits[::7, 3 % K] = logits[::7, :K].max(1).values      # ties: the first maximum wins (torch.argmax)
+    emb = torch.randn(K + 1, 256, generator=g)
+    bit_scale = 0.01
+    lut = (torch.sigmoid(emb) * 2 - 1) * bit_scale
+    mask = torch.randn(rows, 256, generator=g)
+    rec = schedule.step_records('seg', 3)[1]
+    step = _lib.DdpStep()
+    for k, v in rec.items():
+        setattr(step, k, v)
+    d_logits, d_lut, d_mask = logits.to(dev), lut.to(dev), mask.clone().to(dev)
+    _lib.check(lib.ddp_ddim_update_seg(d_logits.data_ptr(), ldl, K, d_lut.data_ptr(), d_mask.data_ptr(), rows, C.byref(step),
+                                       torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    idx = logits[:, :K].argmax(1)
+    x0 = lut[idx]
+    pred_noise = (mask - rec['alpha'] * x0) / max(rec['sigma'], 1e-8)
+    ref = x0 * rec['alpha_next'] + pred_noise * rec['sigma_next']
+    assert max_rel(d_mask.cpu(), ref) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['bf16x3', 'f32', 'bf16x3-unfused-layer', 'ddpm'])
+def test_nan_input_does_not_fault(dev, variant):
+    """a NaN in x spreads over its token's scores through LayerNorm: argmax finds no maximum.  Every update kernel must
+    keep the LUT index in range (NaN propagates, nothing faults) and a clean call afterwards is unaffected."""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    sd = synthetic.make_state_dict('seg', 19, 2, 256, seed=31)
+    h, w = 9, 14
+    x, noise = synthetic.make_inputs(1, h, w, 1, 256, 256, seed=32)
+    cfg = dict(task='seg', h=h, w=w, randsteps=1, timesteps=2, bit_scale=0.01, num_classes=19, accumulation=True,
+               noise_schedule='cosine', diffusion='ddpm' if variant == 'ddpm' else 'ddim')
+    over = VARIANTS[variant] if variant in VARIANTS else {}
+    eng = _engine(cfg, sd, dev, **over)
+    sn = torch.randn(2, 1, 1, 256, h, w).to(dev) if variant == 'ddpm' else None
+    bad = x.clone()
+    bad[0, :, 4, 7] = float('nan')
+    bad[0, 5, 0, 0] = float('inf')
+    out = eng.sample(bad.to(dev), noise.to(dev), sn)
+    torch.cuda.synchronize()                                 # an out-of-range LUT read would fault here
+    assert torch.isnan(out[0, :, 4, 7]).any()
+    if variant != 'ddpm':
+        out = eng.sample(x.to(dev), noise.to(dev), sn).cpu()
+        ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=2, randsteps=1, bit_scale=0.01, accumulation=True)
+        assert max_rel(out, ref) < REL

@@ -262,3 +262,41 @@ def test_inference_and_aug_test_post_processing():
     model.test_cfg = dict(mode='slide', crop_size=(8, 8), stride=(4, 4))
     with pytest.raises(NotImplementedError):
         model.inference(img, [plain], True)
+
+
+def test_full_config_dict_with_a_backbone_entry():
+    """INTEGRATION.md §1 flow with the WHOLE model dict of a shipped config (backbone entry included).  ddp_amd does not
+    implement backbones: a type it does not know is delegated to the host toolbox's ``build_backbone`` when one is
+    importable (tests/test_dropin_reference_registry.py runs that against the reference's registries), an already built
+    nn.Module passes through, and with neither the failure names what was tried."""
+    backbone = dict(type='SwinTransformer', embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7)
+    with pytest.raises(KeyError, match='SwinTransformer.*host toolbox'):
+        ddp_amd.build_segmentor(seg_cfg(backbone=backbone))
+
+    class Stem(torch.nn.Module):                      # a prebuilt backbone module is accepted as is
+        def forward(self, img):
+            return [img]
+    stem = Stem()
+    model = ddp_amd.build_segmentor(seg_cfg(backbone=stem))
+    assert model.backbone is stem
+    with pytest.raises(TypeError):
+        ddp_amd.build_segmentor(seg_cfg(backbone='swin'))
+
+
+def test_bench_gpus_flag_is_not_silently_ignored():
+    """`python bench.py --gpus 2` must either run 2 RCCL ranks or fail loudly - never print a 1-GPU line labelled as asked
+    (the flag was parsed and never read).  On this CPU-only box: 'N device(s) required'."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert '2 device(s) required' in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+    # a rendezvous environment that disagrees with the flag is an error too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=600)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
