@@ -69,7 +69,7 @@ class DdpFcnConv(C.Structure):
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
            'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end']
+           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end']
 
 _lib = None
 
@@ -106,6 +106,7 @@ def load():
     lib.ddp_linear_b3.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.ddp_time_embed.argtypes = [C.POINTER(DdpWeights), C.c_int, C.POINTER(C.c_float), C.c_int, _fp, _fp, _fp, _fp]
     lib.ddp_ddim_update_seg.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.POINTER(DdpStep), _fp]
+    lib.ddp_seg_x0_project.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_float, _fp, _fp]
     lib.ddp_seg_postprocess.argtypes = [_fp] + [C.c_int] * 12 + [_fp, _fp]
     lib.ddp_neck_msm_workspace.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     lib.ddp_neck_msm.argtypes = [C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp,
@@ -113,6 +114,9 @@ def load():
     lib.ddp_fcn_head_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     lib.ddp_fcn_head_forward.argtypes = [C.POINTER(DdpFcnConv), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int,
                                          C.c_int, _fp, _fp, _fp]
+    lib.ddp_sample_fcn_workspace.argtypes = [C.POINTER(DdpCfg), C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_sample_fcn.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpFcnConv), C.c_int, C.c_int,
+                                   C.POINTER(DdpStep), _fp, _fp, _fp, _fp, _fp, _fp]
     lib.ddp_neck_fpn_workspace.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(C.c_size_t)]
     lib.ddp_neck_fpn.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]
     lib.ddp_profile_begin.argtypes = [C.c_int]

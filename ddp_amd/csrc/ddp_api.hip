@@ -970,6 +970,18 @@ int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, c
   return launch_seg_update(a, static_cast<hipStream_t>(stream));
 }
 
+int ddp_seg_x0_project(const float* d_scores, int batch, int num_classes, int n_pix, const float* d_embedding, float bit_scale,
+                       float* d_x0, void* stream) {
+  DDP_TRY(check_ptr(d_scores, "scores"));
+  DDP_TRY(check_ptr(d_embedding, "embedding"));
+  DDP_TRY(check_ptr(d_x0, "x0"));
+  if (batch < 1 || num_classes < 1 || n_pix < 1) {
+    set_error("seg_x0_project: bad sizes (batch %d classes %d pixels %d)", batch, num_classes, n_pix);
+    return DDP_E_BADCFG;
+  }
+  return launch_seg_x0_nchw(d_scores, d_embedding, d_x0, batch, num_classes, n_pix, bit_scale, static_cast<hipStream_t>(stream));
+}
+
 int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h, int w, int img_h, int img_w, int crop_h,
                         int crop_w, int out_h, int out_w, int align_corners, int flip, unsigned char* d_seg, void* stream) {
   DDP_TRY(check_ptr(d_scores, "scores"));
@@ -1244,22 +1256,11 @@ int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* byte
   return DDP_OK;
 }
 
-int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
-                         int num_classes, const float* d_feat, const float* d_temb, int maps, int h, int w, float* d_out,
-                         void* d_workspace, void* stream) {
-  if (num_convs < 0 || num_convs > 8 || dilation < 1 || (num_convs > 0 && !convs)) {
-    set_error("fcn_head: num_convs %d / dilation %d out of range", num_convs, dilation);
-    return DDP_E_BADCFG;
-  }
-  DDP_TRY(check_ptr(d_cls_w, "conv_seg weight"));
-  DDP_TRY(check_ptr(d_feat, "feat"));
-  DDP_TRY(check_ptr(d_out, "out"));
-  DDP_TRY(check_ptr(d_workspace, "workspace"));
-  FcnLayout o;
-  DDP_TRY(fcn_layout(maps, h, w, num_classes, static_cast<char*>(d_workspace), &o));
-  hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
+// FCNHeadWithTime on token-major rows: o.x0 (M,256) in -> o.logits (M, ldl) (fcn_head_with_time.py:285-305, eval mode)
+int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
+                    int num_classes, const float* d_temb, int maps, int h, int w, const FcnLayout& o, hipStream_t st) {
   const int N = h * w, M = maps * N;
-  DDP_TRY(launch_nchw_to_tok(d_feat, o.x0, maps, 256, N, st));
   float* cur = o.x0;
   float* nxt = o.x1;
   for (int i = 0; i < num_convs; ++i) {
@@ -1291,8 +1292,169 @@ int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation,
   SplitW wc;
   wc.p = o.wcls;
   wc.comp_stride = size_t(num_classes) * 256;
-  DDP_TRY(launch_b3_linear(o.q_sb, wc, d_cls_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, num_classes, 256, st, TAG_HEAD));
+  return launch_b3_linear(o.q_sb, wc, d_cls_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, num_classes, 256, st, TAG_HEAD);
+}
+
+// sampler loop around the FCN head: the head's own workspace first, then the loop's buffers
+struct FcnLoopLayout {
+  FcnLayout head;
+  float *tin, *u, *hid, *temb, *lut, *wx, *wm, *xtok, *xproj, *mask, *prob, *snoise;
+  unsigned short *wx_split, *wm_split, *in_sb;
+  size_t bytes;
+};
+int fcn_loop_layout(const ddp_cfg* c, char* base, FcnLoopLayout* o) {
+  const int R = c->batch * c->randsteps, N = c->h * c->w, Kc = c->num_classes, Cx = c->feat_channels;
+  DDP_TRY(fcn_layout(R, c->h, c->w, Kc, base, &o->head));
+  size_t off = o->head.bytes;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  auto takef = [&](size_t floats) { return reinterpret_cast<float*>(take(floats * sizeof(float))); };
+  const size_t M = size_t(R) * N, Mp = (M + 255) / 256 * 256, MB = size_t(c->batch) * N, MBp = (MB + 255) / 256 * 256;
+  o->tin = takef(DDP_MAX_STEPS);
+  o->u = takef(size_t(c->timesteps) * DDP_SINU_FEATS);
+  o->hid = takef(size_t(c->timesteps) * DDP_TIME_DIM);
+  o->temb = takef(size_t(c->timesteps) * DDP_TIME_DIM);
+  o->lut = takef(size_t(Kc + 1) * 256);
+  o->wx = takef(size_t(256) * Cx);
+  o->wm = takef(size_t(256) * 256);
+  o->wx_split = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * Cx * 2));
+  o->wm_split = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 256 * 2));
+  o->xtok = takef(MB * Cx);
+  o->xproj = takef(MB * 256);
+  o->mask = takef(M * 256);
+  o->prob = takef(M * o->head.ldl);
+  o->snoise = takef(c->sampler == DDP_SAMPLER_DDPM ? M * 256 : 0);
+  const size_t sb_a = MBp * Cx, sb_b = Mp * 256;
+  o->in_sb = reinterpret_cast<unsigned short*>(take((sb_a > sb_b ? sb_a : sb_b) * 6));
+  o->bytes = off;
+  return DDP_OK;
+}
+int validate_fcn_loop(const ddp_cfg* cfg, int num_convs, int dilation) {
+  if (!cfg) {
+    set_error("cfg is NULL");
+    return DDP_E_NULL;
+  }
+  ddp_cfg c = *cfg;
+  c.num_layers = 1;                       // the encoder depth is meaningless here
+  DDP_TRY(validate(&c));
+  if (cfg->task != DDP_TASK_SEG || cfg->head_h != cfg->h || cfg->head_w != cfg->w) {
+    set_error("sample_fcn: segmentation only (FCNHeadWithTime is a segmentation head)");
+    return DDP_E_BADCFG;
+  }
+  if (num_convs < 0 || num_convs > 8 || dilation < 1) {
+    set_error("sample_fcn: num_convs %d / dilation %d out of range", num_convs, dilation);
+    return DDP_E_BADCFG;
+  }
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
+                         int num_classes, const float* d_feat, const float* d_temb, int maps, int h, int w, float* d_out,
+                         void* d_workspace, void* stream) {
+  if (num_convs < 0 || num_convs > 8 || dilation < 1 || (num_convs > 0 && !convs)) {
+    set_error("fcn_head: num_convs %d / dilation %d out of range", num_convs, dilation);
+    return DDP_E_BADCFG;
+  }
+  DDP_TRY(check_ptr(d_cls_w, "conv_seg weight"));
+  DDP_TRY(check_ptr(d_feat, "feat"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  FcnLayout o;
+  DDP_TRY(fcn_layout(maps, h, w, num_classes, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = h * w;
+  DDP_TRY(launch_nchw_to_tok(d_feat, o.x0, maps, 256, N, st));
+  DDP_TRY(fcn_head_tokens(convs, num_convs, dilation, d_cls_w, d_cls_b, num_classes, d_temb, maps, h, w, o, st));
   return launch_finalize_nchw(o.logits, o.ldl, d_out, maps, 1, N, num_classes, 1.0f, st);
+}
+
+int ddp_sample_fcn_workspace(const ddp_cfg* cfg, int num_convs, int dilation, size_t* bytes) {
+  DDP_TRY(validate_fcn_loop(cfg, num_convs, dilation));
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  FcnLoopLayout o;
+  DDP_TRY(fcn_loop_layout(cfg, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                   const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
+                   void* d_workspace, void* stream) {
+  DDP_TRY(validate_fcn_loop(cfg, num_convs, dilation));
+  if (!weights || !steps || (num_convs > 0 && !convs)) {
+    set_error("sample_fcn: weights / steps / convs is NULL");
+    return DDP_E_NULL;
+  }
+  DDP_TRY(check_ptr(weights->transform_w, "transform_w"));
+  DDP_TRY(check_ptr(weights->transform_b, "transform_b"));
+  DDP_TRY(check_ptr(weights->embedding, "embedding"));
+  DDP_TRY(check_ptr(weights->head_w, "conv_seg weight"));
+  DDP_TRY(check_ptr(weights->time1_w, "time_mlp.1"));
+  DDP_TRY(check_ptr(weights->time3_w, "time_mlp.3"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  DDP_TRY(check_ptr(d_x, "x"));
+  DDP_TRY(check_ptr(d_noise, "noise"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (cfg->sampler == DDP_SAMPLER_DDPM) DDP_TRY(check_ptr(d_step_noise, "step_noise"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FcnLoopLayout o;
+  DDP_TRY(fcn_loop_layout(cfg, static_cast<char*>(d_workspace), &o));
+  const int B = cfg->batch, r = cfg->randsteps, K = cfg->timesteps, Kc = cfg->num_classes, Cx = cfg->feat_channels;
+  const int N = cfg->h * cfg->w, R = B * r, M = R * N;
+  // constants: time embeddings of every step, x0 LUT, the two column blocks of the concat-conv
+  float tin[DDP_MAX_STEPS];
+  for (int s = 0; s < K; ++s) tin[s] = steps[s].time_in;
+  DDP_TRY(launch_write_floats(tin, K, o.tin, st));
+  DDP_TRY(time_embed_dev(weights, 0, o.tin, K, o.u, o.hid, o.temb, nullptr, st));
+  DDP_TRY(launch_build_lut(weights->embedding, o.lut, Kc + 1, cfg->bit_scale, st));
+  DDP_TRY(launch_pack_cols(weights->transform_w, Cx + 256, 0, 256, Cx, o.wx, st));
+  DDP_TRY(launch_pack_cols(weights->transform_w, Cx + 256, Cx, 256, 256, o.wm, st));
+  DDP_TRY(launch_split_weights(o.wx, Cx, 256, Cx, o.wx_split, st));
+  DDP_TRY(launch_split_weights(o.wm, 256, 256, 256, o.wm_split, st));
+  SplitW wpx, wpm;
+  wpx.p = o.wx_split;
+  wpx.comp_stride = size_t(256) * Cx;
+  wpm.p = o.wm_split;
+  wpm.comp_stride = size_t(256) * 256;
+  // loop-invariant half of the concat-conv (ddp.py:223-224 with the x columns hoisted), start noise -> token-major
+  DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, B, Cx, N, st));
+  DDP_TRY(launch_row_to_sb(o.xtok, Cx, o.in_sb, B * N, Cx, st));
+  DDP_TRY(launch_b3_linear(o.in_sb, wpx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, B * N, 256, Cx, st, TAG_XPROJ));
+  DDP_TRY(launch_nchw_to_tok(d_noise, o.mask, R, 256, N, st));
+  for (int s = 0; s < K; ++s) {
+    const ddp_step& sp = steps[s];
+    // feat = transform(cat[x, mask_t]) -> the head's token-major input
+    DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M, 256, st));
+    DDP_TRY(launch_b3_linear(o.in_sb, wpm, nullptr, o.xproj, 256, r * N, N, o.head.x0, 256, M, 256, 256, st, TAG_XPROJ));
+    DDP_TRY(fcn_head_tokens(convs, num_convs, dilation, weights->head_w, weights->head_b, Kc, o.temb + size_t(s) * DDP_TIME_DIM, R,
+                            cfg->h, cfg->w, o.head, st));
+    SegUpdateArgs a;
+    a.logits = o.head.logits;
+    a.ldl = o.head.ldl;
+    a.num_classes = Kc;
+    a.lut = o.lut;
+    a.mask = o.mask;
+    a.prob = o.prob;
+    a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
+    a.step_noise = nullptr;
+    a.sampler = cfg->sampler;
+    a.st = sp;
+    a.rows = M;
+    if (cfg->sampler == DDP_SAMPLER_DDPM && sp.ddpm_add_noise) {
+      DDP_TRY(launch_nchw_to_tok(d_step_noise + size_t(s) * M * 256, o.snoise, R, 256, N, st));
+      a.step_noise = o.snoise;
+    }
+    DDP_TRY(launch_seg_update(a, st));
+  }
+  if (cfg->accumulation) return launch_finalize_nchw(o.prob, o.head.ldl, d_out, B, r, N, Kc, float(r * K), st);
+  return launch_finalize_nchw(o.head.logits, o.head.ldl, d_out, B, r, N, Kc, float(r), st);
 }
 
 }  // extern "C"

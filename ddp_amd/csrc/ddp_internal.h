@@ -168,6 +168,8 @@ struct SegUpdateArgs {
   int rows;
 };
 int launch_seg_update(const SegUpdateArgs& a, hipStream_t st);
+// x0 = (sigmoid(E[argmax_k scores]) * 2 - 1) * bit_scale, NCHW (B,K,N) -> (B,256,N)
+int launch_seg_x0_nchw(const float* scores, const float* emb, float* out, int B, int K, int N, float bit_scale, hipStream_t st);
 struct SegPostArgs {
   const float* logits;      // (B,K,h,w)
   int B, K, h, w;

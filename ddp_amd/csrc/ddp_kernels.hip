@@ -928,6 +928,29 @@ __global__ void __launch_bounds__(256) k_seg_update(SegUpdateArgs a) {
   *reinterpret_cast<f32x4*>(mp) = mn;
 }
 
+// x0 projection alone, NCHW in / out (segmentors/ddp.py:235-237; the self-aligned pre-pass of
+// segmentors/self_aligned_ddp.py:160-164): idx = argmax_k scores[b][k][n] (first maximum), out[b][c][n] =
+// (sigmoid(E[idx][c]) * 2 - 1) * bit_scale.  One thread per pixel: score reads and map writes are coalesced over n.
+__global__ void __launch_bounds__(256) k_seg_x0_nchw(const float* __restrict__ scores, const float* __restrict__ emb,
+                                                      float* __restrict__ out, int K, int N, float bit_scale) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= N) return;
+  const float* sp = scores + size_t(b) * K * N + n;
+  float best = -INFINITY;
+  int bi = 0;                                         // a row without a maximum (all NaN) keeps class 0: in range
+  for (int k = 0; k < K; ++k) {
+    const float v = sp[size_t(k) * N];
+    if (v > best) {
+      best = v;
+      bi = k;
+    }
+  }
+  const float* e = emb + size_t(bi) * 256;
+  float* op = out + size_t(b) * 256 * N + n;
+  for (int c = 0; c < 256; ++c) op[size_t(c) * N] = (sigmoidf_(e[c]) * 2.0f - 1.0f) * bit_scale;
+}
+
 // out[b][k][n] = (sum_ri prob[(b*r+ri)*N + n][k]) / div ; block = 64 tokens, LDS transpose
 __global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__ prob, int ldl, float* __restrict__ out,
                                                         int r, int N, int K, float div) {
@@ -1220,6 +1243,10 @@ int launch_write_floats(const float* host_vals, int n, float* out, hipStream_t s
 int launch_seg_update(const SegUpdateArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_seg_update, dim3(cdiv(a.rows, 4)), dim3(256), 0, st, a);
   return check_launch("k_seg_update");
+}
+int launch_seg_x0_nchw(const float* scores, const float* emb, float* out, int B, int K, int N, float bit_scale, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_x0_nchw, dim3(cdiv(N, 256), B), dim3(256), 0, st, scores, emb, out, K, N, bit_scale);
+  return check_launch("k_seg_x0_nchw");
 }
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st) {

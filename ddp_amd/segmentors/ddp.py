@@ -265,6 +265,38 @@ class DDP(nn.Module, _SamplerMixin):
 @SEGMENTORS.register_module()
 class SelfAlignedDDP(DDP):
     """segmentation/mmseg/models/segmentors/self_aligned_ddp.py:48-129: the self-aligned variant differs from DDP only
-    in ``forward_train`` (:131-186, out of scope); its inference surface - constructor kwargs, state_dict keys,
-    ``encode_decode`` / ``ddim_sample`` / ``ddpm_sample`` - is DDP's, so the two Cityscapes ``*_aligned`` configs
-    resolve to the same MI355X path."""
+    in ``forward_train`` (:131-186); its inference surface - constructor kwargs, state_dict keys, ``encode_decode`` /
+    ``ddim_sample`` / ``ddpm_sample`` - is DDP's, so the two Cityscapes ``*_aligned`` configs resolve to the same MI355X
+    path.  The one piece of ``forward_train`` that is an inference pass - the no-grad "self-aligned denoising" pre-pass
+    (:150-164) - is exposed as ``self_aligned_predict``."""
+
+    @torch.no_grad()
+    def self_aligned_predict(self, x, noise=None, return_logits=False):
+        """self_aligned_ddp.py:150-164: ONE decoder pass at t = 1 on pure noise, then the x0 projection:
+            feat = transform(cat[x, noise]); logits = decode_head(feat, time_mlp(log_snr(1)))
+            preds = (sigmoid(embedding_table(argmax(logits))) * 2 - 1) * bit_scale
+        x (b,256,h,w) -> preds (b,256,h,w) [, logits (b,K,h,w)].  ``noise`` (b,256,h,w) replaces ``torch.randn_like(x)``.
+        Runs as a 1-step sampler call (the step's t_now is 1 for every K; no update, no accumulation) followed by
+        ``ddp_seg_x0_project``."""
+        import ctypes as C
+
+        from .. import _lib
+        self._check_feature(x)
+        b, c, h, w = x.shape
+        if noise is None:
+            noise = torch.randn_like(x)
+
+        def factory():
+            from ..engine import DDPEngine
+            return DDPEngine(self.hot_path_state_dict(), 'seg', h=h, w=w, batch=b, randsteps=1, timesteps=1,
+                             num_classes=self.num_classes, feat_channels=256, bit_scale=self.bit_scale,
+                             noise_schedule=self.noise_schedule, sampler='ddim', accumulation=False, device=x.device)
+        eng = self._get_engine(('self_aligned', b, h, w, str(x.device), self.bit_scale, self.noise_schedule), factory)
+        logits = eng.sample(x.contiguous().float(), noise.reshape(b, 1, c, h, w).contiguous().float())
+        preds = torch.empty((b, 256, h, w), dtype=torch.float32, device=x.device)
+        emb = self.embedding_table.weight.detach().float().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().ddp_seg_x0_project(logits.data_ptr(), b, self.num_classes, h * w, emb.data_ptr(),
+                                                      C.c_float(self.bit_scale), preds.data_ptr(),
+                                                      torch.cuda.current_stream(x.device).cuda_stream))
+        return (preds, logits) if return_logits else preds

@@ -181,6 +181,12 @@ int ddp_time_embed(const ddp_weights* weights, int num_layers, const float* time
 int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, const float* d_lut,
                         float* d_mask, int rows, const ddp_step* step, void* stream);
 
+/* x0 projection alone (segmentors/ddp.py:235-237), NCHW: d_x0 (B,256,h,w) = (sigmoid(embedding[argmax_k d_scores]) * 2 - 1) *
+ * bit_scale for d_scores (B,K,h,w).  With the scores of ONE decoder pass at t = 1 this is the self-aligned pre-pass of
+ * SelfAlignedDDP (segmentors/self_aligned_ddp.py:150-164: t = 1 head forward -> argmax -> embedding -> bit scaling). */
+int ddp_seg_x0_project(const float* d_scores, int batch, int num_classes, int n_pix, const float* d_embedding,
+                       float bit_scale, float* d_x0, void* stream);
+
 /* Post-loop epilogue of the segmentor, fused: replaces
  *   resize(out, img.shape[2:]) (segmentors/ddp.py:124-128), whole_inference's crop to img_shape + resize to
  *   ori_shape (encoder_decoder.py:236-248), softmax (:277), flip (:278-285) and argmax (:296).
@@ -237,6 +243,16 @@ int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* byte
 int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
                          int num_classes, const float* d_feat /* (maps,256,h,w) */, const float* d_temb /* (1024) or NULL */,
                          int maps, int h, int w, float* d_out /* (maps,num_classes,h,w) */, void* d_workspace, void* stream);
+
+/* The K-step sampler with FCNHeadWithTime as the decode head: what `DDP.ddim_sample` / `ddpm_sample`
+ * (segmentors/ddp.py:215-290) compute when `_decode_head_forward_test` (:192-196) dispatches to
+ * `FCNHeadWithTime.forward_test` (decode_heads/fcn_head_with_time.py:327-343).  Same inputs, outputs, schedule scalars and
+ * x0 projection / update / accumulation as ddp_sample; cfg->task must be DDP_TASK_SEG, cfg->num_layers is ignored;
+ * `weights` supplies transform, time_mlp, embedding and conv_seg (head_w / head_b), `convs` the head's ConvWithTimeModules. */
+int ddp_sample_fcn_workspace(const ddp_cfg* cfg, int num_convs, int dilation, size_t* bytes);
+int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                   const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
+                   void* d_workspace, void* stream);
 
 /* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
