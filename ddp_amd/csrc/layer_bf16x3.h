@@ -407,6 +407,52 @@ k_layer(LayerArgs la) {
   const std::integral_constant<int, 0> I0{};
   const std::integral_constant<int, 1> I1{};
   const std::integral_constant<int, 2> I2{};
+  // EXPERIMENT (untested on hardware): both tall stages of a 64-row chunk with an EARLY hand-over between them.  The
+  // classic stage ends with "wait for stage q+1's DMA; barrier" and the next one starts with six exposed ds_reads.  Here
+  // the wait + barrier sit in front of the LAST block of stage q (11 of stage q+2's 12 pieces are in flight then:
+  // vmcnt(11)); nothing reads stage q's ring slot after that barrier, because the last block's fragment re-reads fetch
+  // block 0 of stage q+1 instead - so the slot may be overwritten by stage q+3's DMA as before, and stage q+1 starts with
+  // its operands already in registers.
+  auto tall_pair = [&](f32x16& a0, f32x16& a1) __attribute__((always_inline)) {
+    u32x4 w[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[t][c] = frag1(slot, c, t, 0);
+#pragma unroll
+    for (int s1 = 0; s1 < 2; ++s1) {
+      stage_begin(nxt(nxt(slot)));
+      const int nslot = nxt(slot);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool nb = b + 1 < 8;
+        const bool hand = s1 == 0 && b == 7;                    // fetch block 0 of the second stage
+        const int rs = hand ? nslot : slot, rb = hand ? 0 : b + 1;
+        const int kb = s1 * 8 + b;
+        if (hand) {
+          __builtin_amdgcn_s_waitcnt(0x0F7B);                   // vmcnt(11)
+          __syncthreads();
+        }
+        auto fill = [&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          if (k == 0 && (nb || hand)) w[0][2] = frag1(rs, 2, 0, rb);
+          if (k == 1 && (nb || hand)) w[1][2] = frag1(rs, 2, 1, rb);
+          if (k == 4 && (nb || hand)) w[0][1] = frag1(rs, 1, 0, rb);
+          if (k == 5 && (nb || hand)) w[1][1] = frag1(rs, 1, 1, rb);
+          if (k == 10 && (nb || hand)) w[0][0] = frag1(rs, 0, 0, rb);
+          if (k == 11 && (nb || hand)) w[1][0] = frag1(rs, 0, 1, rb);
+          if (k == 3) dma(b, b + 1);
+          if (k == 8 && b < 4) dma(8 + b, 9 + b);
+        };
+        DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], fill)
+      }
+      if (s1 == 1) {
+        wait_vm12();
+        __syncthreads();
+      }
+      slot = nxt(slot);
+    }
+  };
   auto bias_init = [&](f32x16 (&a)[2], int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -444,8 +490,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         bias_init(lg[c], c);
-        tall_stage(lg[c][0], lg[c][1], I0);
-        tall_stage(lg[c][0], lg[c][1], I1);
+        tall_pair(lg[c][0], lg[c][1]);
       }
       const int m = m_base + j;
       const bool valid = m < M;
@@ -592,40 +637,49 @@ k_layer(LayerArgs la) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
       }
-    auto p0_stage = [&](int st) __attribute__((always_inline)) {
+    // (EXPERIMENT: every stage but the last hands over early, see tall_pair)
+    u32x4 w[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+    auto p0_stage = [&](int st, auto lastc) __attribute__((always_inline)) {
+      constexpr bool last = decltype(lastc)::value != 0;
       stage_begin(nxt(nxt(slot)));
+      const int nslot = nxt(slot);
       const int stn = st + 1 < 8 ? st + 1 : 7;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
-      u32x4 w[2][3];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
           const int blk = ks * 4 + tp;
-          const bool nb = blk + 1 < 8;
-          const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+          const bool hand = !last && blk == 7;
+          const bool nb = blk + 1 < 8 || hand;
+          const int rs = hand ? nslot : slot;
+          const int tp2 = hand ? 0 : (tp + 1 < 4 ? tp + 1 : 0), ks2 = hand ? 0 : (tp + 1 < 4 ? ks : ks + 1);
+          if (hand) {
+            __builtin_amdgcn_s_waitcnt(0x0F7B);                   // vmcnt(11): the next stage's image and sn have landed
+            __syncthreads();
+          }
           auto fill = [&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
-            if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
-            if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
-            if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
-            if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
-            if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
-            if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
+            if (k == 0 && nb) w[0][2] = frag2(rs, 2, 2 * tp2, ks2);
+            if (k == 1 && nb) w[1][2] = frag2(rs, 2, 2 * tp2 + 1, ks2);
+            if (k == 4 && nb) w[0][1] = frag2(rs, 1, 2 * tp2, ks2);
+            if (k == 5 && nb) w[1][1] = frag2(rs, 1, 2 * tp2 + 1, ks2);
+            if (k == 10 && nb) w[0][0] = frag2(rs, 0, 2 * tp2, ks2);
+            if (k == 11 && nb) w[1][0] = frag2(rs, 0, 2 * tp2 + 1, ks2);
             if (k == 3) dma(blk, blk + 1);
             if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
           };
           DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2], fill)
         }
-      wait_vm12();
+      if (last) wait_vm12();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -633,10 +687,10 @@ k_layer(LayerArgs la) {
           asm volatile("" : "+v"(sn[ks][c]));
           sc[ks][c] = sn[ks][c];
         }
-      __syncthreads();
+      if (last) __syncthreads();
       slot = nxt(slot);
     };
-    for (int st = 0; st < 6; ++st) p0_stage(st);
+    for (int st = 0; st < 6; ++st) p0_stage(st, I0);
     if constexpr (MODE == 2) {
       // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
       f32x4 xr[8][4];
@@ -650,8 +704,8 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) xr[t][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
       }
-      p0_stage(6);
-      p0_stage(7);
+      p0_stage(6, I0);
+      p0_stage(7, I1);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -673,8 +727,8 @@ k_layer(LayerArgs la) {
     for (int b = 0; b < 16; ++b)
 #pragma unroll
       for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
-    p0_stage(6);
-    p0_stage(7);
+    p0_stage(6, I0);
+    p0_stage(7, I1);
 
     // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)
     {
@@ -730,8 +784,7 @@ k_layer(LayerArgs la) {
     for (int hc = 0; hc < 16; ++hc) {
       f32x16 acc1[2];
       bias_init(acc1, hc);
-      tall_stage(acc1[0], acc1[1], I0);
-      tall_stage(acc1[0], acc1[1], I1);
+      tall_pair(acc1[0], acc1[1]);
       // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2)).
       // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: four elements per pair of
       // blocks, 4 x 18 single instructions + 6 packs handed out slot by slot (GELU_SCHED).
@@ -742,14 +795,16 @@ k_layer(LayerArgs la) {
         for (int e = 0; e < 8; ++e) xg[e] = acc1[0][e];
         gelu_split8_packed(xg, hcur[0], hcur[1], hcur[2]);
       }
+      // (EXPERIMENT: early hand-over between the two wide stages, see tall_pair)
+      u32x4 w[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         stage_begin(nxt(nxt(slot)));
-        u32x4 w[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+        const int nslot = nxt(slot);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int kb = s2 * 2 + ks;
@@ -766,16 +821,22 @@ k_layer(LayerArgs la) {
               constexpr int half = decltype(halfc)::value;
               const int tp = 2 * tpp + half;
               const int blk = ks * 4 + tp;
-              const bool nb = blk + 1 < 8;
-              const int tp2 = tp + 1 < 4 ? tp + 1 : 0, ks2 = tp + 1 < 4 ? ks : ks + 1;
+              const bool hand = s2 == 0 && blk == 7;            // fetch block 0 of the second wide stage
+              const bool nb = blk + 1 < 8 || hand;
+              const int rs = hand ? nslot : slot;
+              const int tp2 = hand ? 0 : (tp + 1 < 4 ? tp + 1 : 0), ks2 = hand ? 0 : (tp + 1 < 4 ? ks : ks + 1);
+              if (hand) {
+                __builtin_amdgcn_s_waitcnt(0x0F7B);               // vmcnt(11)
+                __syncthreads();
+              }
               auto fill = [&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                if (k == 0 && nb) w[0][2] = frag2(slot, 2, 2 * tp2, ks2);
-                if (k == 1 && nb) w[1][2] = frag2(slot, 2, 2 * tp2 + 1, ks2);
-                if (k == 4 && nb) w[0][1] = frag2(slot, 1, 2 * tp2, ks2);
-                if (k == 5 && nb) w[1][1] = frag2(slot, 1, 2 * tp2 + 1, ks2);
-                if (k == 10 && nb) w[0][0] = frag2(slot, 0, 2 * tp2, ks2);
-                if (k == 11 && nb) w[1][0] = frag2(slot, 0, 2 * tp2 + 1, ks2);
+                if (k == 0 && nb) w[0][2] = frag2(rs, 2, 2 * tp2, ks2);
+                if (k == 1 && nb) w[1][2] = frag2(rs, 2, 2 * tp2 + 1, ks2);
+                if (k == 4 && nb) w[0][1] = frag2(rs, 1, 2 * tp2, ks2);
+                if (k == 5 && nb) w[1][1] = frag2(rs, 1, 2 * tp2 + 1, ks2);
+                if (k == 10 && nb) w[0][0] = frag2(rs, 0, 2 * tp2, ks2);
+                if (k == 11 && nb) w[1][0] = frag2(rs, 0, 2 * tp2 + 1, ks2);
                 if (k == 3) dma(blk, blk + 1);
                 if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
                 if (kb < 3) {
@@ -808,8 +869,10 @@ k_layer(LayerArgs la) {
             for (int c = 0; c < 3; ++c) hcur[c] = hn[c];
           }
         }
-        wait_vm12();
-        __syncthreads();
+        if (s2 == 1) {
+          wait_vm12();
+          __syncthreads();
+        }
         slot = nxt(slot);
       }
     }
@@ -890,8 +953,7 @@ k_layer(LayerArgs la) {
       for (int vc = 0; vc < 4; ++vc) {
         f32x16 a[2];
         bias_init(a, 16 + vc);
-        tall_stage(a[0], a[1], I0);
-        tall_stage(a[0], a[1], I1);
+        tall_pair(a[0], a[1]);
         if (valid) {
           float* dst = la.v_out + vrow * 256 + vc * 64 + 4 * h;
 #pragma unroll
@@ -918,8 +980,7 @@ k_layer(LayerArgs la) {
             pos[t][g] = *reinterpret_cast<const f32x4*>(la.py + pi * 96 + col) + *reinterpret_cast<const f32x4*>(la.px + pj * 96 + col);
           }
         if (sc2 == 0) {
-          tall_stage(a[0], a[1], I0);
-          tall_stage(a[0], a[1], I1);
+          tall_pair(a[0], a[1]);
         } else {                                               // columns 64..95 as one split-K stage: a[0] + a[1]
 #pragma unroll
           for (int r = 0; r < 16; ++r) a[1][r] = 0.f;
