@@ -366,6 +366,84 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb_pad(const flo
   }
 }
 
+// EXPERIMENT (round 2, untested on hardware): the same padded gather with the lanes of a wave mapped to EIGHT x-adjacent
+// tokens of ONE head (lane = token * 8 + channel quad) and a loop over the heads, instead of one token x eight heads.
+// Consecutive tap instructions of a wave then touch the same few cache lines (corner x+1 of token i is corner x of token
+// i+1 when neighbouring tokens carry similar offsets), so most taps should hit L1 instead of taking the L1-miss path that
+// scripts/ubench/gather_ta.hip shows saturating at 17-19 B/clk/CU.  Block = 4 waves = one 32-token SB group.
+__global__ void __launch_bounds__(256) k_msda_gather_sb_pad_t8(const float* __restrict__ vpad, const float* __restrict__ samp,
+                                                                unsigned short* __restrict__ out_sb, int rows, int n_tok, int h,
+                                                                int w) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tk = lane >> 3;                                   // token of the wave's 8
+  const int cq = (lane & 7) * 4;
+  const int m_base = blockIdx.x * 32;
+  const int jj = wave * 8 + tk;
+  const int m = m_base + jj;
+  const int wp = w + 2;
+  const size_t img_floats = size_t(h + 2) * wp * 256;
+  const float xmax = float(w), ymax = float(h);
+  const bool valid = m < rows;
+  const int mm = valid ? m : rows - 1;
+  const char* vimg = reinterpret_cast<const char*>(vpad + size_t(mm / n_tok) * img_floats);
+  const float* sp = samp + size_t(mm) * DDP_SAMP_STRIDE;
+#pragma unroll 2
+  for (int hd = 0; hd < 8; ++hd) {
+    const f32x4 c01 = *reinterpret_cast<const f32x4*>(sp + hd * 8);
+    const f32x4 c23 = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
+    const f32x4 aw = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+    const float xs[4] = {c01[0], c01[2], c23[0], c23[2]};
+    const float ys[4] = {c01[1], c01[3], c23[1], c23[3]};
+    const unsigned lane_off = unsigned((hd * 32 + cq) * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float x = __builtin_amdgcn_fmed3f(xs[p], -1.0f, xmax), y = __builtin_amdgcn_fmed3f(ys[p], -1.0f, ymax);
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const float gx = 1.f - fx, gy = 1.f - fy;
+      const unsigned o00 = unsigned((int(yf) + 1) * wp + int(xf) + 1) * 1024u + lane_off;
+      const f32x4 v00 = *reinterpret_cast<const f32x4*>(vimg + o00);
+      const f32x4 v01 = *reinterpret_cast<const f32x4*>(vimg + o00 + 1024u);
+      const f32x4 v10 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u);
+      const f32x4 v11 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u + 1024u);
+      const f32x4 sv = v00 * (gy * gx) + v01 * (gy * fx) + v10 * (fy * gx) + v11 * (fy * fx);
+      acc += sv * aw[p];
+    }
+    if (!valid) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + hd * 32 + cq) = acc;
+  }
+  __syncthreads();
+  char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 256 * 192;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int item = r * 256 + threadIdx.x;                   // (b, lane') with lane' = (h', j)
+    const int b = item >> 6, l2 = item & 63;
+    const int j = l2 & 31, hh = l2 >> 5;
+    const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
+    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
+    unsigned short p[3][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      split3(lo4[u], p[0][u], p[1][u], p[2][u]);
+      split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
+    }
+    char* base = gbase + size_t(b) * 3 * 1024 + l2 * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uint4 v;
+      v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+      v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+      v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+      v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+      *reinterpret_cast<uint4*>(base + c * 1024) = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Post-loop epilogue of the segmentor, fused: bilinear resize of the low-resolution class
 // scores to the (padded) image size (segmentors/ddp.py:124-128), crop to img_shape + bilinear resize to ori_shape
@@ -1176,6 +1254,11 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                               hipStream_t st) {
+  static const bool t8 = getenv("DDP_GATHER_T8") && atoi(getenv("DDP_GATHER_T8")) != 0;   // EXPERIMENT, see the kernel
+  if (t8) {
+    hipLaunchKernelGGL(k_msda_gather_sb_pad_t8, dim3(cdiv(rows, 32)), dim3(256), 0, st, vpad, samp, out_sb, rows, n_tok, h, w);
+    return check_launch("k_msda_gather_sb_pad_t8");
+  }
   hipLaunchKernelGGL(k_msda_gather_sb_pad, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, vpad, samp, out_sb, rows, n_tok, h,
                      w);
   return check_launch("k_msda_gather_sb_pad");
