@@ -69,9 +69,9 @@ class DdpFcnConv(C.Structure):
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
            'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end']
+           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
-_lib = None
+_libs = {}
 
 
 class DdpError(RuntimeError):
@@ -83,12 +83,13 @@ def lib_path():
     return os.environ.get('DDP_LIB_PATH') or _build.LIB_PATH
 
 
-def load():
-    """Load (once) and return the shared library; raises if it is missing - there is no CPU path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = lib_path()
+def load(path=None):
+    """Load (once per path) and return the shared library; raises if it is missing - there is no CPU path.
+    ``path`` (default: DDP_LIB_PATH or the in-tree build) lets one process hold several builds of the same ABI, which is
+    how scripts/ab_bench.py compares code states on one GPU box."""
+    path = os.path.abspath(path or lib_path())
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise DdpError(f'{path} not found: build it with `python -m ddp_amd.build` '
                        '(hipcc --offload-arch=gfx950); ddp_amd has no non-HIP fallback')
@@ -121,16 +122,17 @@ def load():
     lib.ddp_neck_fpn.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]
     lib.ddp_profile_begin.argtypes = [C.c_int]
     lib.ddp_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.ddp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     for n in EXPORTS:
         if n not in ('ddp_last_error',):
             getattr(lib, n).restype = C.c_int if n != 'ddp_last_error' else C.c_char_p
     lib.ddp_last_error.restype = C.c_char_p
     if lib.ddp_abi_version() != ABI_VERSION:
         raise DdpError(f'ABI mismatch: library {lib.ddp_abi_version()} vs binding {ABI_VERSION}')
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise DdpError(f'libddp_mi355x error {rc}: {load().ddp_last_error().decode()}')
+        raise DdpError(f'libddp_mi355x error {rc}: {(lib or load()).ddp_last_error().decode()}')

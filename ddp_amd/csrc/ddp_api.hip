@@ -31,22 +31,26 @@ int check_launch(const char* what) {
 
 // ---- optional event profiler of one GEMM call site (bench.py roofline leg) ----------------------
 namespace {
-constexpr int PROF_MAX = 512;
+constexpr int PROF_MAX = 2048;
+constexpr int PROF_ALL = 255;        // ddp_profile_begin(255): every tagged call site at once (ddp_profile_read per tag)
 struct Prof {
   int tag = -1;
   int n = 0;
   hipEvent_t ev[2 * PROF_MAX];
+  unsigned char rec_tag[PROF_MAX];
+  float ms[PROF_MAX];
   bool created = false;
 } g_prof;
 }  // namespace
 
 void prof_begin(int tag, hipStream_t st) {
-  if (tag != g_prof.tag || g_prof.n >= PROF_MAX) return;
+  if ((tag != g_prof.tag && g_prof.tag != PROF_ALL) || g_prof.n >= PROF_MAX) return;
   (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
 }
 void prof_end(int tag, hipStream_t st) {
-  if (tag != g_prof.tag || g_prof.n >= PROF_MAX) return;
+  if ((tag != g_prof.tag && g_prof.tag != PROF_ALL) || g_prof.n >= PROF_MAX) return;
   (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+  g_prof.rec_tag[g_prof.n] = (unsigned char)tag;
   ++g_prof.n;
 }
 
@@ -523,7 +527,7 @@ const char* ddp_last_error(void) { return g_err; }
 int ddp_abi_version(void) { return DDP_ABI_VERSION; }
 
 int ddp_profile_begin(int tag) {
-  if (tag < 0 || tag >= TAG_COUNT) {
+  if ((tag < 0 || tag >= TAG_COUNT) && tag != PROF_ALL) {
     set_error("profile: unknown tag %d", tag);
     return DDP_E_BADCFG;
   }
@@ -551,10 +555,25 @@ int ddp_profile_end(float* total_ms, int* launches) {
     }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    g_prof.ms[i] = ms;
     tot += ms;
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = n;
+  return DDP_OK;
+}
+
+int ddp_profile_read(int tag, float* total_ms, int* launches) {
+  // after ddp_profile_end: the share of one call site in the records of the last session
+  float tot = 0.f;
+  int cnt = 0;
+  for (int i = 0; i < g_prof.n; ++i)
+    if (g_prof.rec_tag[i] == tag) {
+      tot += g_prof.ms[i];
+      ++cnt;
+    }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
   return DDP_OK;
 }
 

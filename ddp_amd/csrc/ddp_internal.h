@@ -36,7 +36,7 @@ inline int cu_count() {                              // compute units of the CUR
 // call-site tags of the GEMM launches (distinct kernel symbols for rocprofv3; profiler hook ids)
 enum GemmTag {
   TAG_GENERIC = 0, TAG_XPROJ = 1, TAG_FEAT = 2, TAG_VALUE = 3, TAG_SAMP = 4, TAG_OUTPROJ_LN = 5, TAG_FC1 = 6,
-  TAG_FC2_LN = 7, TAG_HEAD = 8, TAG_COUNT = 9
+  TAG_FC2_LN = 7, TAG_HEAD = 8, TAG_GATHER = 9, TAG_COUNT = 10
 };
 // optional per-call-site event timing (ddp_profile_* in the C ABI); no-ops unless armed
 void prof_begin(int tag, hipStream_t st);

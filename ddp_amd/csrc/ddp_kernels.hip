@@ -445,6 +445,236 @@ __global__ void __launch_bounds__(256) k_msda_gather_sb_pad_t8(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-staged gather ("deformable-offset gathers staged through LDS", north_star).  The tap traffic of the wave-per-
+// token kernels above is 16 KiB of L2 -> L1 requests per token for 1 KiB of unique value data; here a block owns a
+// GL_TH x GL_TW tile of tokens of one map and, head by head, stages that head's 128-B slice of the value map for the
+// tile plus a halo into LDS by LDS-DMA (one 1-KiB instruction = 8 pixels x 128 B, coalesced), then serves the 16 bilinear
+// taps of every token from LDS (ds_read_b128, the four corners as immediate offsets of one address).  Fill traffic is
+// (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.7 x 1 KiB per token instead of 16 KiB.
+//   * The window of head hd is centred on the tile's MEAN sampling offset of that head (a block reduction over the
+//     tile's 4 x 128 sample points, deterministic): the reference initialises the offsets as a ring of radius 1..4 px per
+//     head (multi_scale_deform_attn.py:233-244), so the points of a head spread +-1.5 px around their mean and
+//     GL_HALO = 3 leaves 1.5 px for the learned, position- and content-dependent part.
+//   * A point whose four corners are not all inside the window is served from global memory with the padded-map
+//     arithmetic of k_msda_gather_sb_pad (wave-uniform branch per point): any offset is handled, only slower.  Both paths
+//     load the same values and combine them in the same order, so the result does not depend on which one ran.
+//   * wave = 8 x-adjacent tokens x 8 channel quads of ONE head (as k_msda_gather_sb_pad_t8); the 32 channels of
+//     (token, head) are K16 blocks 2hd, 2hd+1 of the SB operand: lane pairs (q, q^2) are joined by one DPP quad
+//     permute per register and written straight to HBM as 16-B slots (128-B runs of 8 tokens) - no LDS output tile.
+// Addresses: per-image scalar base + 32-bit offsets (an image's padded map is < 4 GiB).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
+constexpr int GL_TH = 8, GL_TW = 16, GL_HALO = 3;
+constexpr int GL_WW = GL_TW + 2 * GL_HALO + 1;      // 23: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1 corner
+constexpr int GL_WH = GL_TH + 2 * GL_HALO + 1;      // 15
+constexpr int GL_PIX = GL_WW * GL_WH;               // 345 pixels x 128 B
+constexpr int GL_DMA = (GL_PIX + 7) / 8;            // 44 LDS-DMA instructions of 8 pixels
+constexpr int GL_WIN_B = GL_DMA * 1024;
+constexpr int GL_THREADS = 512;
+static_assert(GL_TW == 16 && GL_TH * GL_TW == 128, "the token <-> lane maps below assume 8 x 16 tiles");
+
+__device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(byte_off), "s"(gbase), "s"(lds_dst)
+      : "memory");
+}
+
+__global__ void __launch_bounds__(GL_THREADS, 6) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
+                                                                    unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
+                                                                    int tiles_x, int tiles_y, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char win[GL_WIN_B];
+  __shared__ float msum[8][16];
+  __shared__ int org[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block -> tile map: consecutive block ids land on different XCDs (8 L2s); each XCD walks a contiguous run
+  // of tiles so that neighbouring tiles (shared halos) meet in the same L2
+  const int per = (n_tiles + 7) >> 3;
+  const int tile = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+  if (tile >= n_tiles || (int(blockIdx.x) >> 3) >= per) return;
+  const int tpi = tiles_x * tiles_y;
+  const int img = tile / tpi;
+  const int t2 = tile - img * tpi;
+  const int tyi = t2 / tiles_x;
+  const int y0 = tyi * GL_TH, x0 = (t2 - tyi * tiles_x) * GL_TW;
+  const int wp = w + 2;
+  const float* vimg = vpad + size_t(img) * size_t(h + 2) * wp * 256;
+  const float* simg = samp + size_t(img) * n_tok * DDP_SAMP_STRIDE;
+  const unsigned lds_win = (unsigned)(size_t)(lds_byte_t*)win;
+
+  // ---- mean sampling offset per head over the tile's valid tokens (thread = token x head pair)
+  {
+    const int tl = tid >> 2, hp = tid & 3;
+    const int gy = y0 + (tl >> 4), gx = x0 + (tl & 15);
+    float sx0 = 0.f, sy0 = 0.f, sx1 = 0.f, sy1 = 0.f;
+    if (gy < h && gx < w) {
+      const float* sp = simg + size_t(gy * w + gx) * DDP_SAMP_STRIDE + hp * 16;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(sp + 8), d = *reinterpret_cast<const f32x4*>(sp + 12);
+      const float fx = 4.0f * float(gx), fy = 4.0f * float(gy);
+      sx0 = ((a[0] + a[2]) + (b[0] + b[2])) - fx;
+      sy0 = ((a[1] + a[3]) + (b[1] + b[3])) - fy;
+      sx1 = ((c[0] + c[2]) + (d[0] + d[2])) - fx;
+      sy1 = ((c[1] + c[3]) + (d[1] + d[3])) - fy;
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      sx0 += __shfl_xor(sx0, o, 64);
+      sy0 += __shfl_xor(sy0, o, 64);
+      sx1 += __shfl_xor(sx1, o, 64);
+      sy1 += __shfl_xor(sy1, o, 64);
+    }
+    if (lane < 4) {
+      msum[wave][lane * 4 + 0] = sx0;
+      msum[wave][lane * 4 + 1] = sy0;
+      msum[wave][lane * 4 + 2] = sx1;
+      msum[wave][lane * 4 + 3] = sy1;
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += msum[k][tid];
+    const int nv = min(GL_TW, w - x0) * min(GL_TH, h - y0) * 4;
+    v = v / float(nv);
+    v = fminf(fmaxf(v, -32768.0f), 32768.0f);              // NaN / inf coordinates: any finite origin is fine (fallback path)
+    // tid = hd*2 + axis: window origin in map coordinates
+    org[tid] = ((tid & 1) ? y0 : x0) + int(rintf(v)) - GL_HALO;
+  }
+  __syncthreads();
+
+  const int tk = lane >> 3, q = lane & 7;
+  const float xmax = float(w), ymax = float(h);
+  // this lane's two tokens (groups g = 0, 1: two 8-token runs of the wave's tile row)
+  int mtok[2];
+  bool tval[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int tl = wave * 16 + g * 8 + tk;
+    const int gy = y0 + (tl >> 4), gx = x0 + (tl & 15);
+    tval[g] = gy < h && gx < w;
+    mtok[g] = tval[g] ? gy * w + gx : 0;
+  }
+  const size_t img_tok = size_t(img) * n_tok;
+
+  for (int hd = 0; hd < 8; ++hd) {
+    const int ox = __builtin_amdgcn_readfirstlane(org[2 * hd]), oy = __builtin_amdgcn_readfirstlane(org[2 * hd + 1]);
+    // sample points of (token, head): in flight under the window fill
+    f32x4 c01[2], c23[2], aw[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float* sp = simg + size_t(mtok[g]) * DDP_SAMP_STRIDE;
+      c01[g] = *reinterpret_cast<const f32x4*>(sp + hd * 8);
+      c23[g] = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
+      aw[g] = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+    }
+    // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
+    for (int k = wave; k < GL_DMA; k += GL_THREADS / 64) {
+      int idx = k * 8 + tk;
+      idx = idx < GL_PIX ? idx : GL_PIX - 1;
+      const int py = idx / GL_WW, px = idx - py * GL_WW;
+      const int gyp = min(max(oy + 1 + py, 0), h + 1), gxp = min(max(ox + 1 + px, 0), wp - 1);
+      const unsigned off = unsigned(gyp * wp + gxp) * 1024u + unsigned(hd * 128 + q * 16);
+      gl_dma(vimg, off, lds_win + unsigned(k) * 1024u);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces (and its coordinate loads) landed
+    __syncthreads();
+    // ---- taps
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // tokens outside the map (ragged tile) sample the window centre with a result that is never stored
+      float xs[4] = {c01[g][0], c01[g][2], c23[g][0], c23[g][2]};
+      float ys[4] = {c01[g][1], c01[g][3], c23[g][1], c23[g][3]};
+      int ix[4], iy[4];
+      float fx[4], fy[4];
+      bool inwin = true;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float xv = tval[g] ? xs[p] : float(ox + GL_HALO), yv = tval[g] ? ys[p] : float(oy + GL_HALO);
+        const float x = __builtin_amdgcn_fmed3f(xv, -1.0f, xmax), y = __builtin_amdgcn_fmed3f(yv, -1.0f, ymax);
+        const float xf = floorf(x), yf = floorf(y);
+        fx[p] = x - xf;
+        fy[p] = y - yf;
+        ix[p] = int(xf);
+        iy[p] = int(yf);
+        inwin = inwin && unsigned(ix[p] - ox) < unsigned(GL_WW - 1) && unsigned(iy[p] - oy) < unsigned(GL_WH - 1);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (__builtin_amdgcn_ballot_w64(!inwin) == 0) {          // wave-uniform: every corner of the 8 tokens is staged
+        // explicit LDS address space: a generic pointer would let the two paths be merged into flat loads
+        const lds_byte_t* wb = (const lds_byte_t*)win + (q * 16 - (oy * GL_WW + ox) * 128);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const lds_byte_t* a = wb + (iy[p] * GL_WW + ix[p]) * 128;
+          const f32x4 v00 = *reinterpret_cast<const lds_f32x4_t*>(a);
+          const f32x4 v01 = *reinterpret_cast<const lds_f32x4_t*>(a + 128);
+          const f32x4 v10 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128);
+          const f32x4 v11 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128 + 128);
+          const float gx = 1.f - fx[p], gy = 1.f - fy[p];
+          const f32x4 sv = v00 * (gy * gx) + v01 * (gy * fx[p]) + v10 * (fy[p] * gx) + v11 * (fy[p] * fx[p]);
+          acc += sv * aw[g][p];
+        }
+      } else {                                                  // some corner lies outside the window: padded-map loads
+        const char* vb = reinterpret_cast<const char*>(vimg) + (hd * 128 + q * 16);
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+          const int sel_ix = p == 0 ? ix[0] : p == 1 ? ix[1] : p == 2 ? ix[2] : ix[3];
+          const int sel_iy = p == 0 ? iy[0] : p == 1 ? iy[1] : p == 2 ? iy[2] : iy[3];
+          const float sfx = p == 0 ? fx[0] : p == 1 ? fx[1] : p == 2 ? fx[2] : fx[3];
+          const float sfy = p == 0 ? fy[0] : p == 1 ? fy[1] : p == 2 ? fy[2] : fy[3];
+          const float saw = p == 0 ? aw[g][0] : p == 1 ? aw[g][1] : p == 2 ? aw[g][2] : aw[g][3];
+          const unsigned o00 = unsigned((sel_iy + 1) * wp + sel_ix + 1) * 1024u;
+          const f32x4 v00 = *reinterpret_cast<const f32x4*>(vb + o00);
+          const f32x4 v01 = *reinterpret_cast<const f32x4*>(vb + o00 + 1024u);
+          const f32x4 v10 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u);
+          const f32x4 v11 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u + 1024u);
+          const float gx = 1.f - sfx, gy = 1.f - sfy;
+          const f32x4 sv = v00 * (gy * gx) + v01 * (gy * sfx) + v10 * (sfy * gx) + v11 * (sfy * sfx);
+          acc += sv * saw;
+        }
+      }
+      // join the channel quads q and q^2 (same 16-B slot of the SB operand): DPP quad permute [2,3,0,1]
+      f32x4 oth;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        oth[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[e]), 0x4E, 0xF, 0xF, true));
+      if (tval[g] && (q & 2) == 0) {
+        const int m = int(img_tok) + mtok[g];
+        unsigned short p[3][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          split3(acc[u], p[0][u], p[1][u], p[2][u]);
+          split3(oth[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
+        }
+        // K16 block b = 2 hd + (q >> 2), lane slot (half q & 1, token m & 31) of 32-token group m >> 5
+        char* base = reinterpret_cast<char*>(out_sb) + size_t(m >> 5) * 256 * 192 + size_t(2 * hd + (q >> 2)) * 3 * 1024 +
+                     ((q & 1) * 32 + (m & 31)) * 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          uint4 v;
+          v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+          v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+          v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+          v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+          *reinterpret_cast<uint4*>(base + c * 1024) = v;
+        }
+      }
+    }
+    __syncthreads();                                       // every wave is done reading before the next head's fill
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Post-loop epilogue of the segmentor, fused: bilinear resize of the low-resolution class
 // scores to the (padded) image size (segmentors/ddp.py:124-128), crop to img_shape + bilinear resize to ori_shape
 // (encoder_decoder.py:236-248), softmax (:277, monotone: skipped), flip (:278-285), argmax (:296) -> uint8 map.
@@ -1254,13 +1484,22 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                               hipStream_t st) {
-  static const bool t8 = getenv("DDP_GATHER_T8") && atoi(getenv("DDP_GATHER_T8")) != 0;   // EXPERIMENT, see the kernel
-  if (t8) {
+  // variants kept selectable for same-box A/B runs (read per call, no cached state): lds (default) | t8 | w8
+  const char* e = getenv("DDP_GATHER");
+  const char mode = e ? e[0] : 'l';
+  prof_begin(TAG_GATHER, st);
+  if (mode == 'l') {
+    const int tiles_x = cdiv(w, GL_TW), tiles_y = cdiv(h, GL_TH);
+    const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_msda_gather_lds, dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok, h, w,
+                       tiles_x, tiles_y, n_tiles);
+  } else if (mode == 't') {
     hipLaunchKernelGGL(k_msda_gather_sb_pad_t8, dim3(cdiv(rows, 32)), dim3(256), 0, st, vpad, samp, out_sb, rows, n_tok, h, w);
-    return check_launch("k_msda_gather_sb_pad_t8");
+  } else {
+    hipLaunchKernelGGL(k_msda_gather_sb_pad, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, vpad, samp, out_sb, rows, n_tok, h,
+                       w);
   }
-  hipLaunchKernelGGL(k_msda_gather_sb_pad, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, vpad, samp, out_sb, rows, n_tok, h,
-                     w);
+  prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_sb_pad");
 }
 int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,

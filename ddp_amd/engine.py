@@ -110,8 +110,8 @@ class DDPEngine:
                  feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
-                 weights=None, gemm=None, fused_layer=None, fused_prologue=None):
-        self.lib = _lib.load()
+                 weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None):
+        self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
@@ -174,8 +174,9 @@ class DDPEngine:
         return (c.batch, c.num_classes, c.head_h, c.head_w)
 
     def prepare(self):
-        _lib.check(self.lib.ddp_prepare(C.byref(self.cfg), C.byref(self.weights.struct), self.steps,
-                                        self.workspace.data_ptr(), self._stream()))
+        with torch.cuda.device(self.device):       # launches go to the CURRENT device: make it the workspace's
+            _lib.check(self.lib.ddp_prepare(C.byref(self.cfg), C.byref(self.weights.struct), self.steps,
+                                            self.workspace.data_ptr(), self._stream()), self.lib)
         self._prepared = True
 
     def sample(self, x, noise, step_noise=None, out=None):
@@ -192,9 +193,12 @@ class DDPEngine:
             self.prepare()
         if out is None:
             out = torch.empty(self.out_shape(), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.ddp_sample(C.byref(c), C.byref(self.weights.struct), self.steps, x.data_ptr(),
-                                       noise.data_ptr(), step_noise.data_ptr() if step_noise is not None else None,
-                                       out.data_ptr(), self.workspace.data_ptr(), self._stream()))
+        if x.device != self.device or noise.device != self.device or out.device != self.device:
+            raise _lib.DdpError(f'engine lives on {self.device}: x / noise / out must be on the same device')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ddp_sample(C.byref(c), C.byref(self.weights.struct), self.steps, x.data_ptr(),
+                                           noise.data_ptr(), step_noise.data_ptr() if step_noise is not None else None,
+                                           out.data_ptr(), self.workspace.data_ptr(), self._stream()), self.lib)
         return out
 
     def head_forward(self, feat, temb):
@@ -207,9 +211,10 @@ class DDPEngine:
             t = temb.reshape(-1, 1024)[0].contiguous()
         shape = (R, 1, c.h, c.w) if self.task == 'depth' else (R, c.num_classes, c.head_h, c.head_w)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.ddp_head_forward(C.byref(c), C.byref(self.weights.struct), feat.data_ptr(),
-                                             t.data_ptr() if t is not None else None, out.data_ptr(),
-                                             self.workspace.data_ptr(), self._stream()))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ddp_head_forward(C.byref(c), C.byref(self.weights.struct), feat.data_ptr(),
+                                                 t.data_ptr() if t is not None else None, out.data_ptr(),
+                                                 self.workspace.data_ptr(), self._stream()), self.lib)
         self._prepared = False      # head_forward rewrites the FiLM slot of step 0
         return out
 
@@ -231,6 +236,7 @@ def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corne
     if out is None:
         out = torch.empty((B, oh, ow), dtype=torch.uint8, device=scores.device)
     lib = _lib.load()
-    _lib.check(lib.ddp_seg_postprocess(scores.data_ptr(), B, K, h, w, H, W, ch, cw, oh, ow, int(bool(align_corners)), fl,
-                                       out.data_ptr(), torch.cuda.current_stream(scores.device).cuda_stream))
+    with torch.cuda.device(scores.device):
+        _lib.check(lib.ddp_seg_postprocess(scores.data_ptr(), B, K, h, w, H, W, ch, cw, oh, ow, int(bool(align_corners)), fl,
+                                           out.data_ptr(), torch.cuda.current_stream(scores.device).cuda_stream))
     return out

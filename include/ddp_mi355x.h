@@ -256,10 +256,12 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
 
 /* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
- * tag: 1 xproj, 2 feat, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN,
- * 8 head conv.  ddp_profile_end synchronises on the recorded events. */
+ * tag: 1 xproj, 2 feat / step prologue, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN / the
+ * layer kernel, 8 head conv / seg tail, 9 deformable gather; 255 = all of them at once.  ddp_profile_end synchronises on
+ * the recorded events and returns the sum over all records; ddp_profile_read then gives one call site's share. */
 int ddp_profile_begin(int tag);
 int ddp_profile_end(float* total_ms, int* launches);
+int ddp_profile_read(int tag, float* total_ms, int* launches);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop
