@@ -310,17 +310,26 @@ k_layer(LayerArgs la) {
     return *reinterpret_cast<const u32x4*>(lbase + slot * LYR_STAGE_B + comp * 16384 + t * 2048 + f2_lane + (((2 * ks + h) ^ ((j >> 2) & 3)) << 4));
   };
 
+  const float* bias_s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + LYR_BIAS_OFF);
+  int ht = h;
+  // (the lane id is produced by a volatile asm: the builtin pair is pure, so hipcc computes it once at kernel entry,
+  // spills THAT and reloads it here - 16 B of scratch and four in-order reloads per tile; the table base and the lane's
+  // table index are re-derived with it for the same reason)
   auto refresh = [&]() __attribute__((always_inline)) {
-    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     lane = int(l);
     j = lane & 31;
     h = lane >> 5;
+    ht = h;
     voff0 = unsigned(lane * 16);
     voff1 = voff0 + 4096;
     voff2 = voff0 + 8192;
     f1_lane = j * 256;
     f2_lane = j * 64;
+    unsigned tab_off = LYR_BIAS_OFF;
+    asm volatile("" : "+v"(tab_off));
+    bias_s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + tab_off);
   };
 
   // One block = 12 MFMAs on a tile pair (two independent accumulator chains, 6 split products each) with a filler
@@ -364,12 +373,9 @@ k_layer(LayerArgs la) {
   }
   wait_vm0();
   __syncthreads();
-  const float* bias_s0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + LYR_BIAS_OFF);
-  const float* bias_s = bias_s0;
 
   u32x4 xa[16][3];
   f32x16 acc2[8];
-  int ht = h;
 
   // acc (+)= W[64 rows x 256 k] . xa over two "tall" stages; the ring's look-ahead is fetched on the way.
   // s1 = 2: ONE "split-K" stage of 32 output rows - image rows 0..31 hold k 0..127, rows 32..63 the SAME outputs' k 128..255 -
@@ -468,14 +474,7 @@ k_layer(LayerArgs la) {
     const size_t grp = size_t(tile) * (LYR_BM / 32) + wave;    // this wave's 32-token group
     // opaque per tile: otherwise the (tile-invariant) reads of the per-channel table are hoisted out of the tile
     // loop - ~800 values per lane - and spilled to scratch
-    {
-      unsigned tab_off = LYR_BIAS_OFF;
-      asm volatile("" : "+v"(tab_off));
-      bias_s = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + tab_off);
-    }
     refresh();
-    ht = h;                                                    // same for the lane's table index
-    asm volatile("" : "+v"(ht));
     const int m_base = tile * LYR_BM + wave * 32;
     const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
     char* qs = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
@@ -647,11 +646,16 @@ k_layer(LayerArgs la) {
       constexpr bool last = decltype(lastc)::value != 0;
       stage_begin(nxt(nxt(slot)));
       const int nslot = nxt(slot);
-      const int stn = st + 1 < 8 ? st + 1 : 7;
+      // the LAST stage has no successor: no fragment fetch (it used to re-fetch stage 7's own operands - six dead
+      // loads and 24 registers held under the 48 residual loads in flight, which is what tipped the allocator into
+      // spilling one of those residual fragments behind a vmcnt(0))
+      if constexpr (!last) {
+        const int stn = st + 1;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
+          for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -679,15 +683,18 @@ k_layer(LayerArgs la) {
           };
           DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2], fill)
         }
-      if (last) wait_vm12();
+      if constexpr (last) {
+        wait_vm12();
+        __syncthreads();
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          asm volatile("" : "+v"(sn[ks][c]));
-          sc[ks][c] = sn[ks][c];
-        }
-      if (last) __syncthreads();
+          for (int c = 0; c < 3; ++c) {
+            asm volatile("" : "+v"(sn[ks][c]));
+            sc[ks][c] = sn[ks][c];
+          }
+      }
       slot = nxt(slot);
     };
     for (int st = 0; st < 6; ++st) p0_stage(st, I0);
@@ -724,10 +731,14 @@ k_layer(LayerArgs la) {
     // residual fragments: fetched under the last two stages
     u32x4 qa[16][3];
 #pragma unroll
-    for (int b = 0; b < 16; ++b)
+    for (int b = 0; b < 8; ++b)
 #pragma unroll
       for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
     p0_stage(6, I0);
+#pragma unroll
+    for (int b = 8; b < 16; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
     p0_stage(7, I1);
 
     // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)

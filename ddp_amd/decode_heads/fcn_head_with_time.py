@@ -59,22 +59,8 @@ class FCNHeadWithTime(nn.Module):
         self.conv_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
         self._ws = None
 
-    def forward(self, inputs, times):
-        x = inputs[self.in_index] if isinstance(inputs, (list, tuple)) else inputs
-        if not x.is_cuda:
-            raise _lib.DdpError('FCNHeadWithTime: CUDA tensors only (ddp_amd has no CPU path)')
-        if self.training:
-            raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
-        x = x.contiguous().float()
-        R, c, h, w = x.shape
-        assert c == 256
-        temb = None
-        if times is not None:
-            temb = times.reshape(-1, 1024)
-            if temb.shape[0] > 1 and not torch.equal(temb[:1].expand_as(temb), temb):
-                raise NotImplementedError('per-sample time embeddings (the samplers broadcast one time to the batch)')
-            temb = temb[0].contiguous().float()
-        lib = _lib.load()
+    def conv_array(self):
+        """-> (ddp_fcn_conv array of the head's ConvWithTimeModules, list keeping the referenced tensors alive)"""
         keep = []
 
         def ptr(t):
@@ -93,6 +79,30 @@ class FCNHeadWithTime(nn.Module):
             arr[i].bn_var = ptr(bn.running_var) if bn is not None else None
             arr[i].bn_eps = bn.eps if bn is not None else 0.0
             arr[i].time_w, arr[i].time_b = ptr(m.time_mlp[1].weight), ptr(m.time_mlp[1].bias)
+        return arr, keep
+
+    def forward(self, inputs, times):
+        x = inputs[self.in_index] if isinstance(inputs, (list, tuple)) else inputs
+        if not x.is_cuda:
+            raise _lib.DdpError('FCNHeadWithTime: CUDA tensors only (ddp_amd has no CPU path)')
+        if self.training:
+            raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
+        x = x.contiguous().float()
+        R, c, h, w = x.shape
+        assert c == 256
+        temb = None
+        if times is not None:
+            temb = times.reshape(-1, 1024)
+            if temb.shape[0] > 1 and not torch.equal(temb[:1].expand_as(temb), temb):
+                raise NotImplementedError('per-sample time embeddings (the samplers broadcast one time to the batch)')
+            temb = temb[0].contiguous().float()
+        lib = _lib.load()
+        arr, keep = self.conv_array()
+
+        def ptr(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
         nbytes = C.c_size_t(0)
         _lib.check(lib.ddp_fcn_head_workspace(R, h, w, self.num_classes, C.byref(nbytes)))
         if self._ws is None or self._ws.numel() * 4 < nbytes.value or self._ws.device != x.device:

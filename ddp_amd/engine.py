@@ -219,6 +219,59 @@ class DDPEngine:
         return out
 
 
+class FcnSamplerEngine:
+    """The K-step sampler with ``FCNHeadWithTime`` as decode head (``ddp_sample_fcn``): same inputs,
+    schedule and outputs as ``DDPEngine`` for task 'seg'.  ``head`` is a ``ddp_amd.FCNHeadWithTime`` (parameter holder)."""
+
+    def __init__(self, state_dict, head, *, h, w, batch=1, randsteps=1, timesteps=3, num_classes=150, bit_scale=0.01,
+                 time_difference=1, sample_range0=0.0, noise_schedule='cosine', sampler='ddim', accumulation=False,
+                 device=None, head_prefix='decode_head.', lib_path=None):
+        self.lib = _lib.load(lib_path)
+        if not torch.cuda.is_available():
+            raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.weights = PackedWeights(state_dict, 'seg', 0, self.device, head_prefix)      # transform, time_mlp, embedding, conv_seg
+        self.head = head
+        self.convs, self._keep = head.conv_array()
+        for t in self._keep:
+            if t.device != self.device:
+                raise _lib.DdpError(f'FCN head parameters live on {t.device}, engine on {self.device}')
+        cfg = _lib.DdpCfg()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.task, cfg.sampler = _lib.TASK_SEG, SAMPLERS[sampler]
+        cfg.batch, cfg.randsteps, cfg.timesteps, cfg.num_layers = batch, randsteps, timesteps, 0
+        cfg.num_classes, cfg.feat_channels = num_classes, 256
+        cfg.h = cfg.head_h = h
+        cfg.w = cfg.head_w = w
+        cfg.gemm_mode, cfg.flags = _lib.GEMM_BF16X3, 0
+        cfg.accumulation, cfg.bit_scale = int(bool(accumulation)), bit_scale
+        self.cfg, self.sampler = cfg, sampler
+        recs = schedule.step_records('seg', timesteps, time_difference, sample_range0, noise_schedule, sampler)
+        self.steps = (_lib.DdpStep * timesteps)()
+        for i, r in enumerate(recs):
+            for k, v in r.items():
+                setattr(self.steps[i], k, v)
+        nbytes = C.c_size_t(0)
+        _lib.check(self.lib.ddp_sample_fcn_workspace(C.byref(cfg), head.num_convs, head.dilation, C.byref(nbytes)), self.lib)
+        self.workspace = torch.empty(nbytes.value // 4 + 64, dtype=torch.float32, device=self.device)
+
+    def sample(self, x, noise, step_noise=None, out=None):
+        c = self.cfg
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (c.batch, 256, c.h, c.w)
+        assert noise.is_cuda and noise.is_contiguous() and noise.numel() == c.batch * c.randsteps * 256 * c.h * c.w
+        if self.sampler == 'ddpm':
+            assert step_noise is not None and step_noise.is_contiguous() and step_noise.numel() == c.timesteps * noise.numel()
+        if out is None:
+            out = torch.empty((c.batch, c.num_classes, c.h, c.w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ddp_sample_fcn(C.byref(c), C.byref(self.weights.struct), self.convs, self.head.num_convs,
+                                               self.head.dilation, self.steps, x.data_ptr(), noise.data_ptr(),
+                                               step_noise.data_ptr() if step_noise is not None else None, out.data_ptr(),
+                                               self.workspace.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+                       self.lib)
+        return out
+
+
 def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corners=False, flip=None, out=None):
     """Fused post-loop epilogue: class map (B,out_h,out_w) uint8 from scores (B,K,h,w).
 

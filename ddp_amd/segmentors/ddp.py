@@ -112,7 +112,16 @@ class DDP(nn.Module, _SamplerMixin):
 
     def _engine_for(self, b, h, w, device, sampler):
         def factory():
-            from ..engine import DDPEngine
+            from ..engine import DDPEngine, FcnSamplerEngine
+            from ..decode_heads.fcn_head_with_time import FCNHeadWithTime
+            if isinstance(self.decode_head, FCNHeadWithTime):
+                # any registered head goes through _decode_head_forward_test in the reference (ddp.py:192-196); here the
+                # loop around FCNHeadWithTime is its own C entry (ddp_sample_fcn)
+                return FcnSamplerEngine(self.hot_path_state_dict(), self.decode_head, h=h, w=w, batch=b,
+                                        randsteps=self.randsteps, timesteps=self.timesteps, num_classes=self.num_classes,
+                                        bit_scale=self.bit_scale, time_difference=self.time_difference,
+                                        sample_range0=self.sample_range[0], noise_schedule=self.noise_schedule,
+                                        sampler=sampler, accumulation=self.accumulation, device=device)
             return DDPEngine(self.hot_path_state_dict(), 'seg', h=h, w=w, batch=b, randsteps=self.randsteps,
                              timesteps=self.timesteps, num_classes=self.num_classes, feat_channels=256,
                              bit_scale=self.bit_scale, time_difference=self.time_difference,

@@ -194,6 +194,14 @@ def make_fcn_state_dict(num_convs, num_classes, with_norm, concat_input, seed):
     return sd
 
 
+def make_fcn_segmentor_state_dict(num_convs, num_classes, with_norm, concat_input, seed):
+    """Hot-path state_dict of ``DDP(decode_head=FCNHeadWithTime)``: the segmentor's own parameters
+    (transform, time_mlp, embedding_table) + the FCN head's under ``decode_head.``."""
+    sd = {k: v for k, v in make_state_dict('seg', num_classes, 0, 256, seed=seed).items() if not k.startswith('decode_head.')}
+    sd.update({'decode_head.' + k: v for k, v in make_fcn_state_dict(num_convs, num_classes, with_norm, concat_input, seed).items()})
+    return sd
+
+
 def make_fcn_inputs(maps, h, w, seed):
     g = torch.Generator().manual_seed(50_000 + seed)
     return torch.randn((maps, 256, h, w), generator=g), torch.randn((1, 1024), generator=g)

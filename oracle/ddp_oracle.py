@@ -258,9 +258,10 @@ def x0_from_logits_seg(logits, sd, bit_scale):
 
 def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time_difference=1,
                     sample_range0=0.0, noise_schedule='cosine', accumulation=False,
-                    core='gridsample', trace=None):
+                    core='gridsample', trace=None, head=None):
     """SEGDDP:215-246 for ONE image.  x (1,256,h,w); noise (r,256,h,w) replaces the in-method
-    ``torch.randn`` (SEGDDP:220).  -> (1,K,h,w)."""
+    ``torch.randn`` (SEGDDP:220).  -> (1,K,h,w).  ``head(feat, temb) -> logits`` replaces the decode head that
+    ``_decode_head_forward_test`` (SEGDDP:192-196) dispatches to (default: DeformableHeadWithTime)."""
     log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
     xr = x.repeat(randsteps, 1, 1, 1)
     mask_t = noise.clone()
@@ -277,7 +278,7 @@ def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
         alpha_next, sigma_next = log_snr_to_alpha_sigma(log_snr_next.view(-1, 1, 1, 1))
         temb = time_mlp(log_snr, sd)
         layer_trace = [] if trace is not None else None
-        logits = head_forward_seg(feat, temb, sd, core, layer_trace)
+        logits = head(feat, temb) if head is not None else head_forward_seg(feat, temb, sd, core, layer_trace)
         x0 = x0_from_logits_seg(logits, sd, bit_scale)
         pred_noise = (mask_t - alpha * x0) / sigma.clamp(min=1e-8)
         mask_t = x0 * alpha_next + pred_noise * sigma_next
@@ -292,9 +293,9 @@ def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
 
 def ddpm_sample_seg(x, noise, step_noise, sd, timesteps=3, randsteps=1, bit_scale=0.01,
                     time_difference=1, sample_range0=0.0, noise_schedule='cosine', accumulation=False,
-                    core='gridsample'):
+                    core='gridsample', head=None):
     """SEGDDP:248-290.  ``step_noise`` (timesteps, r,256,h,w) replaces the per-step
-    ``torch.randn_like`` (SEGDDP:280)."""
+    ``torch.randn_like`` (SEGDDP:280).  ``head``: see ddim_sample_seg."""
     log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
     xr = x.repeat(randsteps, 1, 1, 1)
     mask_t = noise.clone()
@@ -311,7 +312,7 @@ def ddpm_sample_seg(x, noise, step_noise, sd, timesteps=3, randsteps=1, bit_scal
         alpha, sigma = log_snr_to_alpha_sigma(pl)
         alpha_next, sigma_next = log_snr_to_alpha_sigma(pln)
         temb = time_mlp(log_snr, sd)
-        logits = head_forward_seg(feat, temb, sd, core)
+        logits = head(feat, temb) if head is not None else head_forward_seg(feat, temb, sd, core)
         x0 = x0_from_logits_seg(logits, sd, bit_scale)
         # times carry the image batch b == 1 (SEGDDP:204-212), so every schedule quantity is a
         # single scalar broadcast over the r noise replicas.
@@ -326,6 +327,26 @@ def ddpm_sample_seg(x, noise, step_noise, sd, timesteps=3, randsteps=1, bit_scal
     if accumulation:
         logits = torch.cat(outs, dim=0)
     return logits.mean(dim=0, keepdim=True)
+
+
+def self_aligned_predict(x, noise, sd, bit_scale=0.01, noise_schedule='cosine', core='gridsample'):
+    """The no-grad "self-aligned denoising" pre-pass of SelfAlignedDDP.forward_train
+    (segmentation/mmseg/models/segmentors/self_aligned_ddp.py:150-164): times = 1, noise = randn_like(x) (injected
+    here), feat = transform(cat[x, noise]), logits = decode_head(feat, time_mlp(log_snr(1))), preds = argmax ->
+    embedding -> (sigmoid*2-1)*bit_scale.  x, noise (b,256,h,w) -> (preds (b,256,h,w), logits (b,K,h,w))."""
+    log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
+    b = x.shape[0]
+    times = torch.ones((b,), dtype=x.dtype)
+    temb = time_mlp(log_snr_fn(times), sd)
+    feat = F.conv2d(torch.cat([x, noise], dim=1), sd['transform.conv.weight'], sd['transform.conv.bias'])
+    logits = head_forward_seg(feat, temb, sd, core)
+    return x0_from_logits_seg(logits, sd, bit_scale), logits
+
+
+def fcn_head_for_sampler(sd, num_convs, dilation=1, prefix='decode_head.'):
+    """``head`` argument of ddim_sample_seg / ddpm_sample_seg for FCNHeadWithTime as the segmentor's decode head
+    (fcn_head_with_time.py:327-343 forward_test -> forward)."""
+    return lambda feat, temb: fcn_head_forward(feat, temb, sd, num_convs, dilation, prefix)
 
 
 def sample_depth(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.1, time_difference=1,

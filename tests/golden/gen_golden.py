@@ -394,17 +394,129 @@ def gen_fpn():
         save(case['name'], dict(task='fpn', **case), arrays)
 
 
+ALIGNED_CASES = [
+    dict(name='aligned_city', h=12, w=18, num_classes=19, batch=2, bit_scale=0.01, noise_schedule='cosine', seed=30),
+    dict(name='aligned_ade_linear', h=9, w=13, num_classes=150, batch=1, bit_scale=0.1, noise_schedule='linear', seed=31),
+]
+
+
+class _Stop(Exception):
+    pass
+
+
+def gen_aligned():
+    """The self-aligned pre-pass of SelfAlignedDDP.forward_train (segmentors/self_aligned_ddp.py:150-164), recorded from the
+    reference class itself: forward_train is entered with the backbone replaced by the seeded feature, ``torch.randn_like``
+    by the seeded noise, and is left (sentinel exception) right after ``embedding_table(preds)`` - the rest of the method is
+    the training loss."""
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in ALIGNED_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.type = 'SelfAlignedDDP'             # same kwargs (the *_aligned Cityscapes configs need mmcls for their backbone)
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.bit_scale = case['bit_scale']
+        m.noise_schedule = case['noise_schedule']
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        assert type(model).__name__ == 'SelfAlignedDDP'
+        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['seed'] + 100)
+        load_hot_path(model, sd)
+        x, noise = synthetic.make_inputs(case['batch'], case['h'], case['w'], 1, 256, 256, seed=case['seed'])
+        noise = noise[:, 0]                                   # (b,256,h,w) = randn_like(x)
+        rec = dict(logits=[], emb=[])
+        wrap_forward(model.decode_head, rec['logits'])
+
+        def grab_emb(mod, i, o):
+            rec['emb'].append(o.clone())
+            raise _Stop()
+        hk = model.embedding_table.register_forward_hook(grab_emb)
+        model.extract_feat = lambda img: [x]
+        img = torch.zeros(case['batch'], 3, 4 * case['h'], 4 * case['w'])
+        try:
+            with RandnPatch(None, [noise]):
+                model.forward_train(img, [dict()] * case['batch'], torch.zeros(case['batch'], 1, 4 * case['h'], 4 * case['w'],
+                                                                               dtype=torch.long))
+        except _Stop:
+            pass
+        hk.remove()
+        e = rec['emb'][0]                                     # (b,h,w,256): embedding_table(argmax(logits))
+        preds = (torch.sigmoid(e.squeeze(1).permute(0, 3, 1, 2)) * 2 - 1) * case['bit_scale']     # :163-164
+        save(case['name'], dict(task='aligned', **case),
+             dict(preds=preds, logits=rec['logits'][0], x_fp=fingerprint(x), noise_fp=fingerprint(noise),
+                  weights_fp=synthetic.checksum(sd)))
+
+
+LOOPFCN_CASES = [
+    dict(name='loopfcn_bn_k3', h=11, w=15, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01, accumulation=True,
+         diffusion='ddim', num_convs=2, with_norm=True, concat_input=False, dilation=1, seed=40),
+    dict(name='loopfcn_nonorm_r2', h=8, w=13, num_classes=150, timesteps=2, randsteps=2, bit_scale=0.01, accumulation=False,
+         diffusion='ddim', num_convs=1, with_norm=False, concat_input=True, dilation=1, seed=41),
+    dict(name='loopfcn_ddpm', h=9, w=10, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01, accumulation=True,
+         diffusion='ddpm', num_convs=2, with_norm=True, concat_input=False, dilation=2, seed=42),
+]
+
+
+def gen_loopfcn():
+    """The reference sampler loop (segmentors/ddp.py:215-290) driving the reference's FCNHeadWithTime
+    (decode_heads/fcn_head_with_time.py:228-343) as decode head.  No shipped config pairs them and the segmentor's
+    constructor reads ``decode_head.in_channels[0]`` (ddp.py:78), which FCNHeadWithTime's int ``in_channels`` does not
+    support - so the segmentor is built from the ADE config and its decode head is then REPLACED by the reference FCN
+    head; ``_decode_head_forward_test`` (:192-196) only needs ``forward_test(inputs, times, img_metas, test_cfg)``."""
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    from mmseg.models.decode_heads import FCNHeadWithTime
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in LOOPFCN_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.timesteps, m.randsteps, m.bit_scale = case['timesteps'], case['randsteps'], case['bit_scale']
+        m.accumulation, m.diffusion = case['accumulation'], case['diffusion']
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        model.decode_head = FCNHeadWithTime(num_convs=case['num_convs'], kernel_size=3, concat_input=case['concat_input'],
+                                            dilation=case['dilation'], in_channels=256, channels=256,
+                                            num_classes=case['num_classes'], in_index=0, dropout_ratio=0.1,
+                                            norm_cfg=dict(type='BN') if case['with_norm'] else None, align_corners=False).eval()
+        # the sampler reads ``decode_head.in_channels[0]`` for the shape of the start noise (ddp.py:220,252); the FCN head
+        # stores an int and no longer reads it after construction
+        model.decode_head.in_channels = [256]
+        sd = synthetic.make_fcn_segmentor_state_dict(case['num_convs'], case['num_classes'], case['with_norm'],
+                                                     case['concat_input'], case['seed'] + 100)
+        load_hot_path(model, sd)
+        x, noise = synthetic.make_inputs(1, case['h'], case['w'], case['randsteps'], 256, 256, seed=case['seed'])
+        step_noise = None
+        if case['diffusion'] == 'ddpm':
+            g = torch.Generator().manual_seed(case['seed'] + 7)
+            step_noise = torch.randn((case['timesteps'], case['randsteps'], 256, case['h'], case['w']), generator=g)
+        logits = []
+        wrap_forward(model.decode_head, logits)
+        with RandnPatch(noise[0], None if step_noise is None else list(step_noise)):
+            out = model.ddim_sample(x, None) if case['diffusion'] == 'ddim' else model.ddpm_sample(x, None)
+        save(case['name'], dict(task='loopfcn', **case),
+             dict(out=out, logits_steps=torch.stack(logits), x_fp=fingerprint(x), noise_fp=fingerprint(noise),
+                  weights_fp=synthetic.checksum(sd)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
-        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn}[args.task]()
+        {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn,
+         'aligned': gen_aligned, 'loopfcn': gen_loopfcn}[args.task]()
 
 
 if __name__ == '__main__':

@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -93,3 +93,31 @@ def load_fpn_case(name):
     assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
     assert np.allclose(np.array([fingerprint(t) for t in levels]), z['levels_fp'], rtol=1e-12)
     return cfg, levels, sd, [torch.from_numpy(z[f'out{l}']) for l in range(4)]
+
+
+def load_aligned_case(name):
+    """Self-aligned pre-pass fixture (self_aligned_ddp.py:150-164): -> (cfg, sd, x, noise, arrays)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    sd = synthetic.make_state_dict('seg', cfg['num_classes'], 6, 256, seed=cfg['seed'] + 100)
+    x, noise = synthetic.make_inputs(cfg['batch'], cfg['h'], cfg['w'], 1, 256, 256, seed=cfg['seed'])
+    noise = noise[:, 0].contiguous()
+    assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
+    assert np.allclose(fingerprint(x), z['x_fp'], rtol=1e-12) and np.allclose(fingerprint(noise), z['noise_fp'], rtol=1e-12)
+    return cfg, sd, x, noise, {k: torch.from_numpy(z[k]) for k in ('preds', 'logits')}
+
+
+def load_loopfcn_case(name):
+    """Sampler loop around FCNHeadWithTime: -> (cfg, sd, x, noise (r,256,h,w), step_noise, arrays)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    sd = synthetic.make_fcn_segmentor_state_dict(cfg['num_convs'], cfg['num_classes'], cfg['with_norm'], cfg['concat_input'],
+                                                 cfg['seed'] + 100)
+    x, noise = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], 256, 256, seed=cfg['seed'])
+    assert abs(synthetic.checksum(sd) - float(z['weights_fp'])) <= 1e-9 * abs(float(z['weights_fp']))
+    assert np.allclose(fingerprint(x), z['x_fp'], rtol=1e-12) and np.allclose(fingerprint(noise), z['noise_fp'], rtol=1e-12)
+    step_noise = None
+    if cfg['diffusion'] == 'ddpm':
+        g = torch.Generator().manual_seed(cfg['seed'] + 7)
+        step_noise = torch.randn((cfg['timesteps'], cfg['randsteps'], 256, cfg['h'], cfg['w']), generator=g)
+    return cfg, sd, x, noise[0], step_noise, {k: torch.from_numpy(z[k]) for k in ('out', 'logits_steps')}

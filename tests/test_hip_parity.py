@@ -457,3 +457,58 @@ def test_nan_input_does_not_fault(dev, variant):
         out = eng.sample(x.to(dev), noise.to(dev), sn).cpu()
         ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=2, randsteps=1, bit_scale=0.01, accumulation=True)
         assert max_rel(out, ref) < REL
+
+
+# ---- self-aligned pre-pass, sampler loop around FCNHeadWithTime ----------------------------------------
+from golden_util import load_aligned_case, load_loopfcn_case  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('aligned'))
+def test_self_aligned_prepass_golden(dev, name):
+    """SelfAlignedDDP.self_aligned_predict (one decoder pass at t = 1 + ddp_seg_x0_project) vs the tensors recorded
+    inside the reference's forward_train (self_aligned_ddp.py:150-164)."""
+    import ddp_amd
+    cfg, sd, x, noise, g = load_aligned_case(name)
+    from test_host_logic import seg_cfg
+    mc = seg_cfg(type='SelfAlignedDDP', bit_scale=cfg['bit_scale'], noise_schedule=cfg['noise_schedule'])
+    mc['decode_head']['num_classes'] = cfg['num_classes']
+    model = ddp_amd.build_segmentor(mc)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    preds, logits = model.self_aligned_predict(x.to(dev), noise.to(dev), return_logits=True)
+    torch.cuda.synchronize()
+    assert max_rel(logits.cpu(), g['logits']) < REL
+    same = (logits.cpu().argmax(1) == g['logits'].argmax(1))
+    assert same.float().mean() > 0.999
+    # x0 rows are exact table look-ups: identical wherever the argmax agrees
+    diff = (preds.cpu() - g['preds']).abs().amax(1)
+    assert float(diff[same].max()) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('loopfcn'))
+def test_sampler_loop_around_fcn_head_golden(dev, name):
+    """DDP(decode_head=FCNHeadWithTime).ddim_sample / ddpm_sample (ddp_sample_fcn) vs the reference sampler driving the
+    reference FCN head."""
+    import ddp_amd
+    cfg, sd, x, noise, step_noise, g = load_loopfcn_case(name)
+    model = ddp_amd.build_segmentor(dict(
+        type='DDP', timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'],
+        accumulation=cfg['accumulation'], diffusion=cfg['diffusion'],
+        decode_head=dict(type='FCNHeadWithTime', num_convs=cfg['num_convs'], concat_input=cfg['concat_input'],
+                         dilation=cfg['dilation'], in_channels=256, channels=256, num_classes=cfg['num_classes'], in_index=0,
+                         norm_cfg=dict(type='BN') if cfg['with_norm'] else None)))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    dn = noise.unsqueeze(0).contiguous().to(dev)
+    if cfg['diffusion'] == 'ddpm':
+        out = model.ddpm_sample(x.to(dev), noise=dn, step_noise=step_noise.unsqueeze(1).contiguous().to(dev))
+    else:
+        out = model.ddim_sample(x.to(dev), noise=dn)
+    torch.cuda.synchronize()
+    assert out.shape == g['out'].shape
+    err = max_rel(out.cpu(), g['out'])
+    agree = (out.cpu().argmax(1) == g['out'].argmax(1)).float().mean().item()
+    print(f'{name}: max-rel {err:.3e}, argmax agreement {agree:.4f}')
+    assert err < REL and agree > 0.999

@@ -150,7 +150,8 @@ def test_error_behaviour_matches_reference():
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ddp_amd import build as b
-    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, '_libs', {})
+    monkeypatch.delenv('DDP_LIB_PATH', raising=False)
     monkeypatch.setattr(b, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.DdpError, match='no non-HIP fallback'):
         _lib.load()

@@ -129,3 +129,32 @@ def test_fpn_golden(name):
     for g, o in zip(got, outs):
         assert g.shape == o.shape
         assert max_rel(g, o) < TOL
+
+
+from golden_util import load_aligned_case, load_loopfcn_case  # noqa: E402
+
+
+@pytest.mark.parametrize('name', case_names('aligned'))
+def test_self_aligned_prepass_golden(name):
+    """the self-aligned pre-pass, fixture recorded inside the reference's SelfAlignedDDP.forward_train
+    (self_aligned_ddp.py:150-164)."""
+    cfg, sd, x, noise, g = load_aligned_case(name)
+    preds, logits = O.self_aligned_predict(x, noise, sd, cfg['bit_scale'], cfg['noise_schedule'])
+    assert preds.shape == g['preds'].shape and logits.shape == g['logits'].shape
+    assert max_rel(logits, g['logits']) < TOL
+    assert max_rel(preds, g['preds']) < TOL
+
+
+@pytest.mark.parametrize('name', case_names('loopfcn'))
+def test_sampler_loop_around_fcn_head_golden(name):
+    """the reference's ddim_sample / ddpm_sample driving the reference's FCNHeadWithTime."""
+    cfg, sd, x, noise, step_noise, g = load_loopfcn_case(name)
+    head = O.fcn_head_for_sampler(sd, cfg['num_convs'], cfg['dilation'])
+    kw = dict(timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'], accumulation=cfg['accumulation'],
+              head=head)
+    if cfg['diffusion'] == 'ddpm':
+        out = O.ddpm_sample_seg(x, noise, step_noise, sd, **kw)
+    else:
+        out = O.ddim_sample_seg(x, noise, sd, **kw)
+    assert out.shape == g['out'].shape
+    assert max_rel(out, g['out']) < TOL
