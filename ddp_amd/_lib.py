@@ -15,7 +15,7 @@ ABI_VERSION = 3
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
-FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE = 1, 2
+FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0 = 1, 2, 4
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
 
@@ -68,7 +68,7 @@ class DdpFcnConv(C.Structure):
 
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
-           'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
+           'ddp_x0_trace', 'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
            'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
 _libs = {}
@@ -100,6 +100,7 @@ def load(path=None):
     lib.ddp_prepare.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp]
     lib.ddp_sample.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp, _fp, _fp,
                                _fp, _fp]
+    lib.ddp_x0_trace.argtypes = [C.POINTER(DdpCfg), _fp, C.POINTER(C.c_void_p)]
     lib.ddp_head_forward.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), _fp, _fp, _fp, _fp, _fp]
     lib.ddp_msda_forward.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]
     lib.ddp_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]

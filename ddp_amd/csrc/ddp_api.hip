@@ -86,6 +86,7 @@ struct Layout {
   float *xproj, *mask, *pred, *feat0, *q, *q1, *v, *s, *samp, *hbuf, *logits, *prob, *snoise, *xtok;
   // bf16x3 mode: split weights and split fragment-major activations
   int b3;
+  unsigned char* x0_trace;       // DDP_FLAG_RECORD_X0: (K, M) argmax class of every step
   bool fused_layer, fused_pro;   // bf16x3: persistent layer kernel / step-prologue kernel in use (cfg->flags)
   SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
       wp_f1[DDP_MAX_LAYERS];
@@ -142,7 +143,7 @@ int validate(const ddp_cfg* c) {
     set_error("bev supports at most 32 classes");
     return DDP_E_BADCFG;
   }
-  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE)) {
+  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -218,6 +219,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->logits = cv.take(o->M * o->ldl);
   o->prob = cv.take(o->M * o->ldl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
+  o->x0_trace = reinterpret_cast<unsigned char*>(
+      cv.take((c->flags & DDP_FLAG_RECORD_X0) && c->task == DDP_TASK_SEG ? (size_t(o->K) * o->M + 3) / 4 : 0));
   o->b3 = c->gemm_mode == DDP_GEMM_BF16X3;
   o->fused_layer = o->b3 && !(c->flags & DDP_FLAG_UNFUSED_LAYER);
   o->fused_pro = o->fused_layer && !(c->flags & DDP_FLAG_UNFUSED_PROLOGUE);
@@ -630,28 +633,30 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   const BevGeom geom = bev_geom(cfg);
 
   // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
-  DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
   if (o.b3) {
-    DDP_TRY(launch_row_to_sb(o.xtok, o.Cx, o.in_sb, o.B * o.N, o.Cx, st));
+    DDP_TRY(launch_nchw_to_sb(d_x, o.in_sb, o.B, o.Cx, o.N, st));       // NCHW -> split fragments in one pass
     DDP_TRY(launch_b3_linear(o.in_sb, o.wp_x, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256, o.Cx, st,
                              TAG_XPROJ));
   } else {
+    DDP_TRY(launch_nchw_to_tok(d_x, o.xtok, o.B, o.Cx, o.N, st));
     DDP_TRY(launch_linear(o.xtok, o.Cx, false, o.wx, o.Cx, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N,
                           256, o.Cx, 0, st, TAG_XPROJ));
   }
+  // seg + DDIM on the bf16x3 engine: conv_seg, argmax, softmax accumulation, x0 LUT and the DDIM update run as the
+  // "tail" mode of the layer kernel, which leaves m_{t_next} as the SB operand of the next step's concat-conv
+  const bool seg_tail = o.fused_layer && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
+                        o.h == o.hh && o.w == o.wh;
   if (cfg->task == DDP_TASK_DEPTH) {
     if (hipMemcpyAsync(o.mask, d_noise, size_t(M0) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("noise copy failed");
       return DDP_E_LAUNCH;
     }
+  } else if (seg_tail) {
+    DDP_TRY(launch_nchw_to_sb(d_noise, o.in_sb, o.R, 256, o.N, st));    // the noisy map only ever exists as SB on this path
   } else {
     DDP_TRY(launch_nchw_to_tok(d_noise, o.mask, o.R, 256, o.N, st));
   }
 
-  // seg + DDIM on the bf16x3 engine: conv_seg, argmax, softmax accumulation, x0 LUT and the DDIM update run as the
-  // "tail" mode of the layer kernel, which leaves m_{t_next} as the SB operand of the next step's concat-conv
-  const bool seg_tail = o.fused_layer && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
-                        o.h == o.hh && o.w == o.wh;
   // tasks whose concat-conv feeds the encoder directly (seg): the head of the step is one kernel with layer 0's projections
   const bool pro_fused = o.fused_pro && cfg->task == DDP_TASK_SEG && o.h == o.hh &&
                          o.w == o.wh;
@@ -663,7 +668,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.s, o.B, o.r, o.N, st));
       DDP_TRY(publish_q(o, o.s, st));
     } else {
-      if (o.b3 && !(seg_tail && s > 0)) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
+      if (o.b3 && !seg_tail) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
       if (cfg->task == DDP_TASK_BEV) {
         if (o.b3)
           DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256, 256, st,
@@ -709,6 +714,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       tl.prob = cfg->accumulation ? o.prob : o.logits;
       tl.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : (s == o.K - 1 ? 3 : 0);
       tl.mask_sb = o.in_sb;
+      tl.x0_idx = (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
       tl.M = M;
       tl.num_classes = o.Kc;
       tl.ldl = o.ldl;
@@ -733,6 +739,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       a.prob = o.prob;
       a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
       a.step_noise = nullptr;
+      a.x0_idx = (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
       a.sampler = cfg->sampler;
       a.st = sp;
       a.rows = M;
@@ -791,6 +798,19 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   } else {
     DDP_TRY(launch_finalize_nchw(o.prob, 32, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r * o.K), st));
   }
+  return DDP_OK;
+}
+
+int ddp_x0_trace(const ddp_cfg* cfg, void* d_workspace, const unsigned char** d_idx) {
+  DDP_TRY(validate(cfg));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  if (!d_idx || !(cfg->flags & DDP_FLAG_RECORD_X0) || cfg->task != DDP_TASK_SEG) {
+    set_error("x0_trace: needs a segmentation cfg with DDP_FLAG_RECORD_X0");
+    return DDP_E_BADCFG;
+  }
+  Layout o;
+  carve(cfg, static_cast<float*>(d_workspace), &o);
+  *d_idx = o.x0_trace;
   return DDP_OK;
 }
 
@@ -983,6 +1003,7 @@ int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, c
   a.prob = nullptr;
   a.prob_mode = 0;
   a.step_noise = nullptr;
+  a.x0_idx = nullptr;
   a.sampler = DDP_SAMPLER_DDIM;
   a.st = *step;
   a.rows = rows;
@@ -1463,6 +1484,7 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
     a.prob = o.prob;
     a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
     a.step_noise = nullptr;
+    a.x0_idx = nullptr;
     a.sampler = cfg->sampler;
     a.st = sp;
     a.rows = M;

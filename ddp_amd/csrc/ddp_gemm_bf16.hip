@@ -214,6 +214,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   la.lut = a.lut;
   la.prob = a.prob;
   la.mask_sb = a.mask_sb;
+  la.x0_idx = a.x0_idx;
   la.num_classes = a.num_classes;
   la.ldl = a.ldl;
   la.prob_mode = a.prob_mode;

@@ -104,6 +104,7 @@ struct TailLaunch {
   const float* lut;
   float* prob;
   unsigned short* mask_sb;
+  unsigned char* x0_idx;        // optional: argmax class per token (diagnostic trace)
   int M, num_classes, ldl, prob_mode;
   float alpha, sigma, alpha_next, sigma_next;
 };
@@ -133,6 +134,8 @@ int launch_row_to_sb(const float* in, int ld, unsigned short* out_sb, int rows, 
 
 // ---- ddp_kernels.hip ----------------------------------------------------------------------------
 int launch_nchw_to_tok(const float* in, float* out, int R, int C, int N, hipStream_t st);
+// NCHW (R,C,N) fp32 -> SB (rows R*N padded to 256, C channels, C % 16 == 0)
+int launch_nchw_to_sb(const float* in, unsigned short* out_sb, int R, int C, int N, hipStream_t st);
 // row-major (rows,256) -> fragment-major
 int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st);
 // ga = gamma*(scale+1), be = beta*(scale+1)+shift for S x L (film (S,L,512) = scale|shift); out (S,L,512) = ga|be
@@ -163,6 +166,7 @@ struct SegUpdateArgs {
   float* prob;          // (M, ldl) accumulated softmax / last logits; may be nullptr
   int prob_mode;        // 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = logits
   const float* step_noise;  // ddpm (M,256) token-major or nullptr
+  unsigned char* x0_idx;    // optional: argmax class per token (diagnostic trace)
   int sampler;
   ddp_step st;
   int rows;

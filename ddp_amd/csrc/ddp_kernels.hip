@@ -147,6 +147,44 @@ __global__ void __launch_bounds__(256) k_row_to_sb(const float* __restrict__ in,
   }
 }
 
+// NCHW (R, C, N) fp32 -> SB directly (k_nchw_to_tok + k_row_to_sb in one pass: the token-major fp32 copy - 1 KiB per
+// token written and read back - is never made).  A block owns 64 consecutive tokens of the flattened (R*N) row space
+// (two SB groups; a group may straddle two maps) x 64 channels (four K16 blocks): coalesced 256-B reads along n into
+// an LDS tile, then 16-B SB slots out.
+__global__ void __launch_bounds__(256) k_nchw_to_sb(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int N,
+                                                     int rows) {
+  __shared__ float tile[64][65];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  {
+    const int m = m0 + tx;
+    const int r = m / N, n = m - r * N;
+    const float* src = in + (size_t(r) * C + c0) * N + n;
+    for (int cc = ty; cc < 64; cc += 4) tile[cc][tx] = (m < rows && c0 + cc < C) ? src[size_t(cc) * N] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * 256 + threadIdx.x;          // (group gi, K16 block bl, lane l2 = (hh, j))
+    const int l2 = item & 63, bl = (item >> 6) & 3, gi = item >> 8;
+    const int j = l2 & 31, hh = l2 >> 5;
+    if (c0 + 16 * bl >= C) continue;
+    unsigned short p[3][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) split3(tile[16 * bl + 8 * (u >> 2) + 4 * hh + (u & 3)][gi * 32 + j], p[0][u], p[1][u], p[2][u]);
+    char* base = reinterpret_cast<char*>(out) + size_t((m0 >> 5) + gi) * C * 192 + size_t((c0 >> 4) + bl) * 3 * 1024 + l2 * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uint4 v;
+      v.x = p[c][0] | (unsigned(p[c][1]) << 16);
+      v.y = p[c][2] | (unsigned(p[c][3]) << 16);
+      v.z = p[c][4] | (unsigned(p[c][5]) << 16);
+      v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+      *reinterpret_cast<uint4*>(base + c * 1024) = v;
+    }
+  }
+}
+
 // LayerNorm affine pre-multiplied by FiLM: out[i] = {gamma*(scale+1) | beta*(scale+1)+shift}, i over (S*L)
 __global__ void k_fold_affine(const float* __restrict__ gamma, const float* __restrict__ beta,
                               const float* __restrict__ film, float* __restrict__ out) {
@@ -465,14 +503,17 @@ __global__ void __launch_bounds__(256) k_msda_gather_sb_pad_t8(const float* __re
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
-constexpr int GL_TH = 8, GL_TW = 16, GL_HALO = 3;
-constexpr int GL_WW = GL_TW + 2 * GL_HALO + 1;      // 23: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1 corner
-constexpr int GL_WH = GL_TH + 2 * GL_HALO + 1;      // 15
-constexpr int GL_PIX = GL_WW * GL_WH;               // 345 pixels x 128 B
-constexpr int GL_DMA = (GL_PIX + 7) / 8;            // 44 LDS-DMA instructions of 8 pixels
-constexpr int GL_WIN_B = GL_DMA * 1024;
 constexpr int GL_THREADS = 512;
-static_assert(GL_TW == 16 && GL_TH * GL_TW == 128, "the token <-> lane maps below assume 8 x 16 tiles");
+// tile GL_TH x GL_TW tokens (128 per block: 8 waves x 2 runs of 8 x-adjacent tokens), halo GL_HALO:
+//   window width  GL_WW = TW + 2 HALO + 1: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1 corner
+template <int TH, int TW, int HALO>
+struct GlGeom {
+  static_assert(TH * TW == 128 && TW % 8 == 0, "128 tokens per tile, rows of whole 8-token runs");
+  static constexpr int WW = TW + 2 * HALO + 1, WH = TH + 2 * HALO + 1;
+  static constexpr int PIX = WW * WH;               // window pixels x 128 B
+  static constexpr int DMA = (PIX + 7) / 8;         // LDS-DMA instructions of 8 pixels (1 KiB)
+  static constexpr int WIN_B = DMA * 1024;
+};
 
 __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, unsigned lds_dst) {
   unsigned keep;
@@ -487,9 +528,12 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
       : "memory");
 }
 
-__global__ void __launch_bounds__(GL_THREADS, 6) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
+template <int GL_TH, int GL_TW, int GL_HALO, int MINW>
+__global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
                                                                     int tiles_x, int tiles_y, int n_tiles) {
+  using G = GlGeom<GL_TH, GL_TW, GL_HALO>;
+  constexpr int GL_WW = G::WW, GL_WH = G::WH, GL_PIX = G::PIX, GL_DMA = G::DMA, GL_WIN_B = G::WIN_B;
   __shared__ __attribute__((aligned(16))) unsigned char win[GL_WIN_B];
   __shared__ float msum[8][16];
   __shared__ int org[16];
@@ -514,7 +558,7 @@ __global__ void __launch_bounds__(GL_THREADS, 6) k_msda_gather_lds(const float* 
   // ---- mean sampling offset per head over the tile's valid tokens (thread = token x head pair)
   {
     const int tl = tid >> 2, hp = tid & 3;
-    const int gy = y0 + (tl >> 4), gx = x0 + (tl & 15);
+    const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
     float sx0 = 0.f, sy0 = 0.f, sx1 = 0.f, sy1 = 0.f;
     if (gy < h && gx < w) {
       const float* sp = simg + size_t(gy * w + gx) * DDP_SAMP_STRIDE + hp * 16;
@@ -561,7 +605,7 @@ __global__ void __launch_bounds__(GL_THREADS, 6) k_msda_gather_lds(const float* 
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int tl = wave * 16 + g * 8 + tk;
-    const int gy = y0 + (tl >> 4), gx = x0 + (tl & 15);
+    const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
     tval[g] = gy < h && gx < w;
     mtok[g] = tval[g] ? gy * w + gx : 0;
   }
@@ -1184,6 +1228,7 @@ __global__ void __launch_bounds__(256) k_seg_update(SegUpdateArgs a) {
   // a row without a maximum (every score NaN or -inf: a NaN in x spreads over the row through LayerNorm) must still index
   // the LUT in range - the NaN then propagates through the update arithmetic instead of faulting (the tail kernel does the same)
   if (bi >= K) bi = 0;
+  if (a.x0_idx && lane == 0) a.x0_idx[m] = (unsigned char)bi;
   if (a.prob && a.prob_mode) {
     float* pr = a.prob + size_t(m) * a.ldl;
     if (a.prob_mode == 3) {
@@ -1443,6 +1488,11 @@ int launch_row_to_sb(const float* in, int ld, unsigned short* out_sb, int rows, 
   hipLaunchKernelGGL(k_row_to_sb, dim3(cdiv(n, 256)), dim3(256), 0, st, in, ld, out_sb, rows, C);
   return check_launch("k_row_to_sb");
 }
+int launch_nchw_to_sb(const float* in, unsigned short* out_sb, int R, int C, int N, hipStream_t st) {
+  const long rows = long(R) * N;
+  hipLaunchKernelGGL(k_nchw_to_sb, dim3(cdiv(rows, 64), cdiv(C, 64)), dim3(256), 0, st, in, out_sb, C, N, int(rows));
+  return check_launch("k_nchw_to_sb");
+}
 int launch_row_to_blk(const float* in, float* out_blk, int rows, hipStream_t st) {
   hipLaunchKernelGGL(k_row_to_blk, dim3(cdiv(rows, 4)), dim3(256), 0, st, in, out_blk, rows);
   return check_launch("k_row_to_blk");
@@ -1489,10 +1539,19 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
   const char mode = e ? e[0] : 'l';
   prof_begin(TAG_GATHER, st);
   if (mode == 'l') {
-    const int tiles_x = cdiv(w, GL_TW), tiles_y = cdiv(h, GL_TH);
-    const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_msda_gather_lds, dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok, h, w,
-                       tiles_x, tiles_y, n_tiles);
+    // l (default) = 8 x 16 tiles, halo 3, 6 waves / SIMD; digits select the other compiled shapes (A/B runs)
+    const char v = e && e[1] ? e[1] : '0';
+    auto go = [&](auto kern, int TH, int TW) {
+      const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+      const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
+      hipLaunchKernelGGL(kern, dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok, h, w, tiles_x, tiles_y,
+                         n_tiles);
+    };
+    if (v == '1') go(k_msda_gather_lds<8, 16, 3, 4>, 8, 16);
+    else if (v == '2') go(k_msda_gather_lds<4, 32, 3, 4>, 4, 32);
+    else if (v == '3') go(k_msda_gather_lds<8, 16, 2, 6>, 8, 16);
+    else if (v == '4') go(k_msda_gather_lds<8, 16, 4, 4>, 8, 16);
+    else go(k_msda_gather_lds<8, 16, 3, 6>, 8, 16);
   } else if (mode == 't') {
     hipLaunchKernelGGL(k_msda_gather_sb_pad_t8, dim3(cdiv(rows, 32)), dim3(256), 0, st, vpad, samp, out_sb, rows, n_tok, h, w);
   } else {

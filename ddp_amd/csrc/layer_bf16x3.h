@@ -77,6 +77,7 @@ struct LayerArgs {
   const float* lut;              // (num_classes + 1, 256): (sigmoid(embedding) * 2 - 1) * bit_scale
   float* prob;                   // (M, ldl) accumulated softmax / last-step scores
   unsigned short* mask_sb;       // SB noisy map m_t (256 ch): read, replaced by m_{t_next}
+  unsigned char* x0_idx;         // optional (DDP_FLAG_RECORD_X0): the step's argmax class per token
   int num_classes, ldl, prob_mode;   // prob_mode: 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = scores
   float alpha, sigma, alpha_next, sigma_next;
   // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
@@ -521,6 +522,7 @@ k_layer(LayerArgs la) {
       }
       // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
       if (!valid || bi >= K) bi = 0;
+      if (la.x0_idx && valid && h == 0) la.x0_idx[m] = (unsigned char)bi;
       // Every global load of the epilogue is issued in a batch ahead of its consumers.  The straightforward loops (load 5,
       // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
       // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores

@@ -110,7 +110,7 @@ class DDPEngine:
                  feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
-                 weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None):
+                 weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False):
         self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -148,6 +148,8 @@ class DDPEngine:
         if fused_prologue is None:
             fused_prologue = os.environ.get('DDP_PROLOGUE_FUSED', '1') != '0'
         cfg.flags = (0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE)
+        if record_x0:
+            cfg.flags |= _lib.FLAG_RECORD_X0
         self.fused_layer = bool(fused_layer)
         cfg.accumulation = int(bool(accumulation))
         cfg.bit_scale, cfg.min_depth, cfg.max_depth, cfg.threshold = bit_scale, min_depth, max_depth, threshold
@@ -200,6 +202,15 @@ class DDPEngine:
                                            noise.data_ptr(), step_noise.data_ptr() if step_noise is not None else None,
                                            out.data_ptr(), self.workspace.data_ptr(), self._stream()), self.lib)
         return out
+
+    def x0_trace(self):
+        """(K, B*r, h, w) uint8: the x0 class every step of the LAST sample() call fed back (needs record_x0=True)."""
+        c = self.cfg
+        p = C.c_void_p()
+        _lib.check(self.lib.ddp_x0_trace(C.byref(c), self.workspace.data_ptr(), C.byref(p)), self.lib)
+        off = p.value - self.workspace.data_ptr()
+        n = c.timesteps * c.batch * c.randsteps * c.head_h * c.head_w
+        return self.workspace.view(torch.uint8)[off:off + n].view(c.timesteps, c.batch * c.randsteps, c.head_h, c.head_w).clone()
 
     def head_forward(self, feat, temb):
         """DeformableHeadWithTime.forward on (R,256,h,w) + (1|R,1024) time embedding."""

@@ -61,7 +61,7 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
 /* ddp_cfg.flags (diagnostics, bf16x3 engine): run the decoder layer / the head of a step as the separate tile GEMMs they
  * were fused from (identical arithmetic per contraction; used by same-box A/B runs and by the parity tests that keep
  * the unfused kernels covered).  UNFUSED_LAYER implies the unfused step head and seg tail as well. */
-enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2 };
+enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4 };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -144,6 +144,13 @@ int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* 
 int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps,
                const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
                void* d_workspace, void* stream);
+
+/* Diagnostic trace (seg, cfg->flags & DDP_FLAG_RECORD_X0): after ddp_sample, *d_idx points at (K, B*r*h*w) uint8 inside
+ * the workspace - the x0 class (argmax of the step's scores, ddp.py:235) every step fed back.  The loop's only
+ * discontinuity is this discrete choice; with it recorded, parity splits into "same decisions -> outputs agree to
+ * rounding" and "decisions differ only where the reference's own top-2 gap is at rounding level"
+ * (tests/test_full_size_parity.py). */
+int ddp_x0_trace(const ddp_cfg* cfg, void* d_workspace, const unsigned char** d_idx);
 
 /* ---- finer-grained entry points (unit tests, and the decode_head plugin surface) ------------- */
 

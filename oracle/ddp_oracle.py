@@ -249,25 +249,30 @@ def head_forward_depth(feat, temb, sd, min_depth=1e-3, core='gridsample', trace=
 # --------------------------------------------------------------------------------------------
 # samplers
 # --------------------------------------------------------------------------------------------
-def x0_from_logits_seg(logits, sd, bit_scale):
-    """SEGDDP:235-237: argmax -> embedding -> (sigmoid*2-1)*bit_scale.  (r,K,h,w)->(r,256,h,w)."""
-    idx = torch.argmax(logits, dim=1)
+def x0_from_logits_seg(logits, sd, bit_scale, idx=None):
+    """SEGDDP:235-237: argmax -> embedding -> (sigmoid*2-1)*bit_scale.  (r,K,h,w)->(r,256,h,w).
+    ``idx`` (r,h,w) replaces the argmax (teacher-forced decisions, see ddim_sample_seg)."""
+    if idx is None:
+        idx = torch.argmax(logits, dim=1)
     e = F.embedding(idx, sd['embedding_table.weight']).permute(0, 3, 1, 2)
     return (torch.sigmoid(e) * 2 - 1) * bit_scale
 
 
 def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time_difference=1,
                     sample_range0=0.0, noise_schedule='cosine', accumulation=False,
-                    core='gridsample', trace=None, head=None):
+                    core='gridsample', trace=None, head=None, x0_index=None):
     """SEGDDP:215-246 for ONE image.  x (1,256,h,w); noise (r,256,h,w) replaces the in-method
     ``torch.randn`` (SEGDDP:220).  -> (1,K,h,w).  ``head(feat, temb) -> logits`` replaces the decode head that
-    ``_decode_head_forward_test`` (SEGDDP:192-196) dispatches to (default: DeformableHeadWithTime)."""
+    ``_decode_head_forward_test`` (SEGDDP:192-196) dispatches to (default: DeformableHeadWithTime).
+    ``x0_index``: optional K maps (r,h,w) of class indices used INSTEAD of argmax(logits) in the x0 projection - the
+    loop's only discrete decision.  Feeding the decisions another implementation took removes the feedback
+    discontinuity from a comparison (everything else is continuous in the inputs)."""
     log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
     xr = x.repeat(randsteps, 1, 1, 1)
     mask_t = noise.clone()
     outs = []
     logits = None
-    for t_now, t_next in sampling_time_pairs(timesteps, time_difference, sample_range0):
+    for step, (t_now, t_next) in enumerate(sampling_time_pairs(timesteps, time_difference, sample_range0)):
         times_now = torch.tensor([t_now], dtype=torch.float32)
         times_next = torch.tensor([t_next], dtype=torch.float32)
         feat = torch.cat([xr, mask_t], dim=1)
@@ -279,7 +284,7 @@ def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
         temb = time_mlp(log_snr, sd)
         layer_trace = [] if trace is not None else None
         logits = head(feat, temb) if head is not None else head_forward_seg(feat, temb, sd, core, layer_trace)
-        x0 = x0_from_logits_seg(logits, sd, bit_scale)
+        x0 = x0_from_logits_seg(logits, sd, bit_scale, None if x0_index is None else x0_index[step].long())
         pred_noise = (mask_t - alpha * x0) / sigma.clamp(min=1e-8)
         mask_t = x0 * alpha_next + pred_noise * sigma_next
         if accumulation:

@@ -4,7 +4,7 @@
 both fp32 operands split exactly into three bf16 pieces, six cross products on the bf16 matrix cores, fp32
 accumulation (ddp_amd/csrc/gemm_bf16x3.h:1-32).  The claim under test is "fp32-class": for every output
 
-    |c - c_fp64| <= C_BOUND * 2^-24 * sum_k |a_k| |w_k|
+    |c - c_fp64| <= c_bound(K) * 2^-24 * sum_k |a_k| |w_k|,   c_bound(K) = 2 sqrt(K)
 
 which is the bound an fp32 dot product with exact products and K fp32 additions satisfies with C ~ K/2 in the worst
 case and ~sqrt(K) typically.  The same inputs go through the exact f32-input MFMA engine (``ddp_linear``) and the
@@ -20,7 +20,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 U = 2.0 ** -24
-C_BOUND = 8.0          # asserted multiple of 2^-24 * sum|a||w|; measured ~1 (printed)
+
+
+def c_bound(k):
+    """asserted multiple of 2^-24 * sum|a||w|.  An fp32 dot product with exact products and K fp32 additions is bounded
+    by ~K/2 and sits at a few sqrt(K)/4 in practice (measured r02b: bf16x3 5.7 .. 8.8, the exact-product fp32 MFMA engine
+    6.4 .. 9.0 at K = 256 .. 1024, worst over 10^5 outputs); 2 sqrt(K) leaves a factor ~4 over the measured worst."""
+    return 2.0 * k ** 0.5
 
 
 def _run(a, w, b, dev, engine):
@@ -76,8 +82,8 @@ def test_b3_normal_operands(m, n, k):
         res[eng] = (float((err / (U * scale)).max()), float(err.max() / ref.abs().max()))
     print(f'N(0,1) {m}x{n}x{k}: bf16x3 max err / (2^-24 sum|a||w|) = {res["b3"][0]:.3f} (max-rel {res["b3"][1]:.2e}); '
           f'fp32 MFMA {res["f32"][0]:.3f} (max-rel {res["f32"][1]:.2e})')
-    assert res['b3'][0] <= C_BOUND
-    assert res['b3'][0] <= 2.0 * res['f32'][0] + 1.0          # not worse than the exact-product fp32 engine
+    assert res['b3'][0] <= c_bound(k)
+    assert res['b3'][0] <= 2.0 * res['f32'][0] + 1.0          # same class as the exact-product fp32 engine
 
 
 def test_b3_wide_dynamic_range():
@@ -88,14 +94,14 @@ def test_b3_wide_dynamic_range():
     m, n, k = 384, 256, 256
     a = _pow2_mixed((m, k), -60, 60, g)
     w = _pow2_mixed((n, k), -3, 3, g)
+    res = {}
     for eng in ('b3', 'f32'):
         out = _run(a, w, None, dev, eng)
         assert torch.isfinite(out).all()
         err, scale, _ = _ratio(out, a, w, None)
-        r = float((err / (U * scale)).max())
-        print(f'wide range ({eng}): max err / (2^-24 sum|a||w|) = {r:.3f}')
-        if eng == 'b3':
-            assert r <= C_BOUND
+        res[eng] = float((err / (U * scale)).max())
+    print(f'wide range: max err / (2^-24 sum|a||w|) = {res["b3"]:.3f} (bf16x3), {res["f32"]:.3f} (fp32 MFMA)')
+    assert res['b3'] <= c_bound(k) and res['b3'] <= 2.0 * res['f32'] + 1.0
 
 
 def test_b3_exact_cancellation():
@@ -113,7 +119,7 @@ def test_b3_exact_cancellation():
     err, scale, ref = _ratio(out, a, w, b)
     r = float((err / (U * scale)).max())
     print(f'cancelling rows: max |out - bias| = {float(err.max()):.3e}, / (2^-24 sum|a||w|) = {r:.3f}')
-    assert r <= C_BOUND
+    assert r <= c_bound(k)
 
 
 def test_b3_tiny_operands_report():
@@ -133,12 +139,12 @@ def test_b3_tiny_operands_report():
     floor = 2.0 ** -126 * w.double().abs().sum(1).max()          # every term's flushed pieces
     print(f'near-subnormal operands: max err / (2^-24 sum|a||w|) = {r:.3f}; max abs err {float(err.max()):.3e}, '
           f'flush floor {float(floor):.3e}')
-    assert bool((err <= C_BOUND * U * scale + floor).all())
+    assert bool((err <= c_bound(k) * U * scale + floor).all())
 
 
 def test_b3_matches_sampler_arithmetic():
-    """transposition / layout probe (identity-like A, asymmetric W) through the split path: exact, since every operand
-    here is representable in one bf16 piece plus zeros"""
+    """transposition / layout probe (identity A, asymmetric W) through the split path: exact - every product is exact and
+    every output has a single non-zero term"""
     dev = torch.device('cuda:0')
     m = n = k = 256
     a = torch.eye(m, k)
