@@ -4,6 +4,7 @@
 // one wave64 owns one token row as 64 x float4: every load / store of a row is a single fully
 // coalesced 1 KiB access and per-token reductions are wave reductions.
 #include <math.h>
+#include <type_traits>
 #include "ddp_internal.h"
 
 namespace ddp {
@@ -323,165 +324,6 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
   }
 }
 
-// Same gather over a ZERO-PADDED value map: value rows live at (i+1)*(w+2) + (j+1) of an (h+2) x (w+2) grid whose
-// border rows are zero (written once; the producer - the layer kernel - only ever stores the interior).  Clamping the
-// sample position to [-1, w] x [-1, h] then makes every tap a plain load: the four validity tests, index clamps and
-// conditional weights per tap of the unpadded kernel (a third of its instructions - the kernel is issue bound) go
-// away, and a tap further out than one pixel lands on a border row with weight 0 or 1, i.e. contributes 0 as in
-// the reference (multi_scale_deform_attn.py:123-128, grid_sample padding_mode='zeros').
-// Addresses are a per-image scalar base + 32-bit offsets.
-__global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb_pad(const float* __restrict__ vpad,
-                                                                        const float* __restrict__ samp,
-                                                                        unsigned short* __restrict__ out_sb, int rows,
-                                                                        int n_tok, int h, int w) {
-  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int hd = lane >> 3;
-  const int cq = (lane & 7) * 4;
-  const int m_base = blockIdx.x * 32;
-  const int wp = w + 2;
-  const size_t img_floats = size_t(h + 2) * wp * 256;
-  const unsigned lane_off = unsigned((hd * 32 + cq) * 4);
-  const float xmax = float(w), ymax = float(h);
-#pragma unroll
-  for (int it = 0; it < 32 / GSB_WAVES; ++it) {
-    const int jj = wave * (32 / GSB_WAVES) + it;
-    const int m = __builtin_amdgcn_readfirstlane(m_base + jj);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (m < rows) {
-      const char* vimg = reinterpret_cast<const char*>(vpad + size_t(m / n_tok) * img_floats);
-      const float* sp = samp + size_t(m) * DDP_SAMP_STRIDE;
-      const f32x4 c01 = *reinterpret_cast<const f32x4*>(sp + hd * 8);
-      const f32x4 c23 = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
-      const f32x4 aw = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
-      const float xs[4] = {c01[0], c01[2], c23[0], c23[2]};
-      const float ys[4] = {c01[1], c01[3], c23[1], c23[3]};
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float x = __builtin_amdgcn_fmed3f(xs[p], -1.0f, xmax), y = __builtin_amdgcn_fmed3f(ys[p], -1.0f, ymax);
-        const float xf = floorf(x), yf = floorf(y);
-        const float fx = x - xf, fy = y - yf;
-        const float gx = 1.f - fx, gy = 1.f - fy;
-        // padded coordinates: (y0 + 1, x0 + 1) in [0, h] x [0, w]; the +1 neighbours stay inside the (h+2) x (w+2) grid
-        const unsigned o00 = unsigned((int(yf) + 1) * wp + int(xf) + 1) * 1024u + lane_off;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(vimg + o00);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(vimg + o00 + 1024u);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u + 1024u);
-        const f32x4 sv = v00 * (gy * gx) + v01 * (gy * fx) + v10 * (fy * gx) + v11 * (fy * fx);
-        acc += sv * aw[p];
-      }
-    }
-    *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + hd * 32 + cq) = acc;
-  }
-  __syncthreads();
-  char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 256 * 192;
-#pragma unroll
-  for (int r = 0; r < 16 / GSB_WAVES; ++r) {
-    const int item = r * 64 * GSB_WAVES + threadIdx.x;        // (b, lane') with lane' = (h', j)
-    const int b = item >> 6, l2 = item & 63;
-    const int j = l2 & 31, hh = l2 >> 5;
-    const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
-    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
-    unsigned short p[3][8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      split3(lo4[u], p[0][u], p[1][u], p[2][u]);
-      split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
-    }
-    char* base = gbase + size_t(b) * 3 * 1024 + l2 * 16;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      uint4 v;
-      v.x = p[c][0] | (unsigned(p[c][1]) << 16);
-      v.y = p[c][2] | (unsigned(p[c][3]) << 16);
-      v.z = p[c][4] | (unsigned(p[c][5]) << 16);
-      v.w = p[c][6] | (unsigned(p[c][7]) << 16);
-      *reinterpret_cast<uint4*>(base + c * 1024) = v;
-    }
-  }
-}
-
-// EXPERIMENT (round 2, untested on hardware): the same padded gather with the lanes of a wave mapped to EIGHT x-adjacent
-// tokens of ONE head (lane = token * 8 + channel quad) and a loop over the heads, instead of one token x eight heads.
-// Consecutive tap instructions of a wave then touch the same few cache lines (corner x+1 of token i is corner x of token
-// i+1 when neighbouring tokens carry similar offsets), so most taps should hit L1 instead of taking the L1-miss path that
-// scripts/ubench/gather_ta.hip shows saturating at 17-19 B/clk/CU.  Block = 4 waves = one 32-token SB group.
-__global__ void __launch_bounds__(256) k_msda_gather_sb_pad_t8(const float* __restrict__ vpad, const float* __restrict__ samp,
-                                                                unsigned short* __restrict__ out_sb, int rows, int n_tok, int h,
-                                                                int w) {
-  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int tk = lane >> 3;                                   // token of the wave's 8
-  const int cq = (lane & 7) * 4;
-  const int m_base = blockIdx.x * 32;
-  const int jj = wave * 8 + tk;
-  const int m = m_base + jj;
-  const int wp = w + 2;
-  const size_t img_floats = size_t(h + 2) * wp * 256;
-  const float xmax = float(w), ymax = float(h);
-  const bool valid = m < rows;
-  const int mm = valid ? m : rows - 1;
-  const char* vimg = reinterpret_cast<const char*>(vpad + size_t(mm / n_tok) * img_floats);
-  const float* sp = samp + size_t(mm) * DDP_SAMP_STRIDE;
-#pragma unroll 2
-  for (int hd = 0; hd < 8; ++hd) {
-    const f32x4 c01 = *reinterpret_cast<const f32x4*>(sp + hd * 8);
-    const f32x4 c23 = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
-    const f32x4 aw = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
-    const float xs[4] = {c01[0], c01[2], c23[0], c23[2]};
-    const float ys[4] = {c01[1], c01[3], c23[1], c23[3]};
-    const unsigned lane_off = unsigned((hd * 32 + cq) * 4);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float x = __builtin_amdgcn_fmed3f(xs[p], -1.0f, xmax), y = __builtin_amdgcn_fmed3f(ys[p], -1.0f, ymax);
-      const float xf = floorf(x), yf = floorf(y);
-      const float fx = x - xf, fy = y - yf;
-      const float gx = 1.f - fx, gy = 1.f - fy;
-      const unsigned o00 = unsigned((int(yf) + 1) * wp + int(xf) + 1) * 1024u + lane_off;
-      const f32x4 v00 = *reinterpret_cast<const f32x4*>(vimg + o00);
-      const f32x4 v01 = *reinterpret_cast<const f32x4*>(vimg + o00 + 1024u);
-      const f32x4 v10 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u);
-      const f32x4 v11 = *reinterpret_cast<const f32x4*>(vimg + o00 + unsigned(wp) * 1024u + 1024u);
-      const f32x4 sv = v00 * (gy * gx) + v01 * (gy * fx) + v10 * (fy * gx) + v11 * (fy * fx);
-      acc += sv * aw[p];
-    }
-    if (!valid) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + hd * 32 + cq) = acc;
-  }
-  __syncthreads();
-  char* gbase = reinterpret_cast<char*>(out_sb) + size_t(blockIdx.x) * 256 * 192;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int item = r * 256 + threadIdx.x;                   // (b, lane') with lane' = (h', j)
-    const int b = item >> 6, l2 = item & 63;
-    const int j = l2 & 31, hh = l2 >> 5;
-    const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
-    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
-    unsigned short p[3][8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      split3(lo4[u], p[0][u], p[1][u], p[2][u]);
-      split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
-    }
-    char* base = gbase + size_t(b) * 3 * 1024 + l2 * 16;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      uint4 v;
-      v.x = p[c][0] | (unsigned(p[c][1]) << 16);
-      v.y = p[c][2] | (unsigned(p[c][3]) << 16);
-      v.z = p[c][4] | (unsigned(p[c][5]) << 16);
-      v.w = p[c][6] | (unsigned(p[c][7]) << 16);
-      *reinterpret_cast<uint4*>(base + c * 1024) = v;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // LDS-staged gather ("deformable-offset gathers staged through LDS", north_star).  The tap traffic of the wave-per-
 // token kernels above is 16 KiB of L2 -> L1 requests per token for 1 KiB of unique value data; here a block owns a
@@ -528,6 +370,12 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
       : "memory");
 }
 
+// Each of a token's 8 lanes does the coordinate arithmetic of ONE sample point (p = q & 3) and the results travel to the
+// other lanes by ds_swizzle (a cross-lane move through the LDS crossbar, no storage) instead of every lane redoing all four
+// points (0.214 -> 0.206 ms, r02d); the 3-way split of the result happens BEFORE the quad exchange (each lane splits its
+// own four values).  Measured shapes (r02c/r02d, C2, ms per launch): 8x16 halo 3 at two blocks per CU 0.206; the same at
+// three blocks per CU (80 registers: spills) 0.232; halo 4 0.215; halo 2 (more fallbacks) 0.251; 4x32 tiles 0.224; a
+// double-buffered 16x16 tile with one 1024-thread block per CU 0.231; the wave-per-token kernels before it 0.278 - 0.314.
 template <int GL_TH, int GL_TW, int GL_HALO, int MINW>
 __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
@@ -613,14 +461,15 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
 
   for (int hd = 0; hd < 8; ++hd) {
     const int ox = __builtin_amdgcn_readfirstlane(org[2 * hd]), oy = __builtin_amdgcn_readfirstlane(org[2 * hd + 1]);
-    // sample points of (token, head): in flight under the window fill
-    f32x4 c01[2], c23[2], aw[2];
+    {
+    // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
+    float px_[2], py_[2], pw_[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const float* sp = simg + size_t(mtok[g]) * DDP_SAMP_STRIDE;
-      c01[g] = *reinterpret_cast<const f32x4*>(sp + hd * 8);
-      c23[g] = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
-      aw[g] = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+      const float* sp = simg + size_t(mtok[g]) * DDP_SAMP_STRIDE + hd * 8;
+      px_[g] = sp[2 * (q & 3)];
+      py_[g] = sp[2 * (q & 3) + 1];
+      pw_[g] = sp[64 - hd * 4 + (q & 3)];                    // (sp already carries + hd * 8)
     }
     // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
     for (int k = wave; k < GL_DMA; k += GL_THREADS / 64) {
@@ -629,7 +478,7 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
       const int py = idx / GL_WW, px = idx - py * GL_WW;
       const int gyp = min(max(oy + 1 + py, 0), h + 1), gxp = min(max(ox + 1 + px, 0), wp - 1);
       const unsigned off = unsigned(gyp * wp + gxp) * 1024u + unsigned(hd * 128 + q * 16);
-      gl_dma(vimg, off, lds_win + unsigned(k) * 1024u);
+      gl_dma(vimg, off, __builtin_amdgcn_readfirstlane(lds_win + unsigned(k) * 1024u));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces (and its coordinate loads) landed
     __syncthreads();
@@ -637,82 +486,100 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // tokens outside the map (ragged tile) sample the window centre with a result that is never stored
-      float xs[4] = {c01[g][0], c01[g][2], c23[g][0], c23[g][2]};
-      float ys[4] = {c01[g][1], c01[g][3], c23[g][1], c23[g][3]};
-      int ix[4], iy[4];
-      float fx[4], fy[4];
-      bool inwin = true;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float xv = tval[g] ? xs[p] : float(ox + GL_HALO), yv = tval[g] ? ys[p] : float(oy + GL_HALO);
-        const float x = __builtin_amdgcn_fmed3f(xv, -1.0f, xmax), y = __builtin_amdgcn_fmed3f(yv, -1.0f, ymax);
-        const float xf = floorf(x), yf = floorf(y);
-        fx[p] = x - xf;
-        fy[p] = y - yf;
-        ix[p] = int(xf);
-        iy[p] = int(yf);
-        inwin = inwin && unsigned(ix[p] - ox) < unsigned(GL_WW - 1) && unsigned(iy[p] - oy) < unsigned(GL_WH - 1);
-      }
+      const float xv = tval[g] ? px_[g] : float(ox + GL_HALO), yv = tval[g] ? py_[g] : float(oy + GL_HALO);
+      const float x = __builtin_amdgcn_fmed3f(xv, -1.0f, xmax), y = __builtin_amdgcn_fmed3f(yv, -1.0f, ymax);
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int ix = int(xf), iy = int(yf);
+      const int rx = ix - ox, ry = iy - oy;
+      const bool inwin = unsigned(rx) < unsigned(GL_WW - 1) && unsigned(ry) < unsigned(GL_WH - 1);
+      // corner weights with the attention weight folded in: (aw gy) gx, (aw gy) fx, (aw fy) gx, (aw fy) fx
+      const float wa = pw_[g] * (1.f - fy), wb = pw_[g] * fy;
+      const float w00 = wa * (1.f - fx), w01 = wa * fx, w10 = wb * (1.f - fx), w11 = wb * fx;
+      const bool staged = __builtin_amdgcn_ballot_w64(!inwin) == 0;       // wave-uniform: every corner of the 8 tokens is in LDS
+      // staged: byte offset of the point's top-left corner in the window; else in the padded map of this image
+      const int aoff = staged ? (ry * GL_WW + rx) * 128 : int(unsigned((iy + 1) * wp + ix + 1) * 1024u + unsigned(hd * 128));
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (__builtin_amdgcn_ballot_w64(!inwin) == 0) {          // wave-uniform: every corner of the 8 tokens is staged
-        // explicit LDS address space: a generic pointer would let the two paths be merged into flat loads
-        const lds_byte_t* wb = (const lds_byte_t*)win + (q * 16 - (oy * GL_WW + ox) * 128);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const lds_byte_t* a = wb + (iy[p] * GL_WW + ix[p]) * 128;
-          const f32x4 v00 = *reinterpret_cast<const lds_f32x4_t*>(a);
-          const f32x4 v01 = *reinterpret_cast<const lds_f32x4_t*>(a + 128);
-          const f32x4 v10 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128);
-          const f32x4 v11 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128 + 128);
-          const float gx = 1.f - fx[p], gy = 1.f - fy[p];
-          const f32x4 sv = v00 * (gy * gx) + v01 * (gy * fx[p]) + v10 * (fy[p] * gx) + v11 * (fy[p] * fx[p]);
-          acc += sv * aw[g][p];
+      auto point = [&](auto ppc, auto stagedc) __attribute__((always_inline)) {
+        // fetch point pp from lane (token, pp) of this token's 8 lanes: lane' = (lane & 0x18) | pp within each 32-lane half
+        // (ds_swizzle bit mode: and_mask [4:0], or_mask [9:5], xor_mask [14:10])
+        constexpr int pat = (decltype(ppc)::value << 5) | 0x18;
+        const int o = __builtin_amdgcn_ds_swizzle(aoff, pat);
+        const float a00 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w00), pat));
+        const float a01 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w01), pat));
+        const float a10 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w10), pat));
+        const float a11 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w11), pat));
+        f32x4 v00, v01, v10, v11;
+        if constexpr (decltype(stagedc)::value) {
+          // explicit LDS address space: a generic pointer would let the two paths be merged into flat loads
+          const lds_byte_t* a = (const lds_byte_t*)win + (o + q * 16);
+          v00 = *reinterpret_cast<const lds_f32x4_t*>(a);
+          v01 = *reinterpret_cast<const lds_f32x4_t*>(a + 128);
+          v10 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128);
+          v11 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128 + 128);
+        } else {
+          const char* vb = reinterpret_cast<const char*>(vimg) + q * 16;
+          const unsigned o00 = unsigned(o);
+          v00 = *reinterpret_cast<const f32x4*>(vb + o00);
+          v01 = *reinterpret_cast<const f32x4*>(vb + o00 + 1024u);
+          v10 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u);
+          v11 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u + 1024u);
         }
-      } else {                                                  // some corner lies outside the window: padded-map loads
-        const char* vb = reinterpret_cast<const char*>(vimg) + (hd * 128 + q * 16);
-#pragma unroll 1
-        for (int p = 0; p < 4; ++p) {
-          const int sel_ix = p == 0 ? ix[0] : p == 1 ? ix[1] : p == 2 ? ix[2] : ix[3];
-          const int sel_iy = p == 0 ? iy[0] : p == 1 ? iy[1] : p == 2 ? iy[2] : iy[3];
-          const float sfx = p == 0 ? fx[0] : p == 1 ? fx[1] : p == 2 ? fx[2] : fx[3];
-          const float sfy = p == 0 ? fy[0] : p == 1 ? fy[1] : p == 2 ? fy[2] : fy[3];
-          const float saw = p == 0 ? aw[g][0] : p == 1 ? aw[g][1] : p == 2 ? aw[g][2] : aw[g][3];
-          const unsigned o00 = unsigned((sel_iy + 1) * wp + sel_ix + 1) * 1024u;
-          const f32x4 v00 = *reinterpret_cast<const f32x4*>(vb + o00);
-          const f32x4 v01 = *reinterpret_cast<const f32x4*>(vb + o00 + 1024u);
-          const f32x4 v10 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u);
-          const f32x4 v11 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u + 1024u);
-          const float gx = 1.f - sfx, gy = 1.f - sfy;
-          const f32x4 sv = v00 * (gy * gx) + v01 * (gy * sfx) + v10 * (sfy * gx) + v11 * (sfy * sfx);
-          acc += sv * saw;
-        }
+        // one explicit fma chain per channel: the same arithmetic on both paths
+        acc = __builtin_elementwise_fma(v00, f32x4{a00, a00, a00, a00}, acc);
+        acc = __builtin_elementwise_fma(v01, f32x4{a01, a01, a01, a01}, acc);
+        acc = __builtin_elementwise_fma(v10, f32x4{a10, a10, a10, a10}, acc);
+        acc = __builtin_elementwise_fma(v11, f32x4{a11, a11, a11, a11}, acc);
+      };
+      if (staged) {
+        point(std::integral_constant<int, 0>{}, std::true_type{});
+        point(std::integral_constant<int, 1>{}, std::true_type{});
+        point(std::integral_constant<int, 2>{}, std::true_type{});
+        point(std::integral_constant<int, 3>{}, std::true_type{});
+      } else {                                                   // rare: one point at a time (4 loads in flight)
+        point(std::integral_constant<int, 0>{}, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        point(std::integral_constant<int, 1>{}, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        point(std::integral_constant<int, 2>{}, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        point(std::integral_constant<int, 3>{}, std::false_type{});
       }
-      // join the channel quads q and q^2 (same 16-B slot of the SB operand): DPP quad permute [2,3,0,1]
-      f32x4 oth;
+      // exact 3-way split of this lane's four channels, THEN the quad exchange with lane q ^ 2 (the other half of the
+      // 16-B slot): 6 packed dwords travel instead of 4 fp32 + a second split
+      unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        oth[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[e]), 0x4E, 0xF, 0xF, true));
+      for (int u = 0; u < 4; ++u) {
+        const unsigned xb = __float_as_uint(acc[u]);
+        hh[u] = xb & 0xFFFF0000u;
+        const float r = acc[u] - __uint_as_float(hh[u]);
+        mm[u] = __float_as_uint(r) & 0xFFFF0000u;
+        ll[u] = __float_as_uint(r - __uint_as_float(mm[u]));
+      }
+      unsigned own[3][2];
+      own[0][0] = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302); own[0][1] = __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302);
+      own[1][0] = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302); own[1][1] = __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302);
+      own[2][0] = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302); own[2][1] = __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302);
+      unsigned oth[3][2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) oth[c][e] = unsigned(__builtin_amdgcn_mov_dpp(int(own[c][e]), 0x4E, 0xF, 0xF, true));
       if (tval[g] && (q & 2) == 0) {
         const int m = int(img_tok) + mtok[g];
-        unsigned short p[3][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          split3(acc[u], p[0][u], p[1][u], p[2][u]);
-          split3(oth[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
-        }
-        // K16 block b = 2 hd + (q >> 2), lane slot (half q & 1, token m & 31) of 32-token group m >> 5
         char* base = reinterpret_cast<char*>(out_sb) + size_t(m >> 5) * 256 * 192 + size_t(2 * hd + (q >> 2)) * 3 * 1024 +
                      ((q & 1) * 32 + (m & 31)) * 16;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           uint4 v;
-          v.x = p[c][0] | (unsigned(p[c][1]) << 16);
-          v.y = p[c][2] | (unsigned(p[c][3]) << 16);
-          v.z = p[c][4] | (unsigned(p[c][5]) << 16);
-          v.w = p[c][6] | (unsigned(p[c][7]) << 16);
+          v.x = own[c][0];
+          v.y = own[c][1];
+          v.z = oth[c][0];
+          v.w = oth[c][1];
           *reinterpret_cast<uint4*>(base + c * 1024) = v;
         }
       }
+    }
     }
     __syncthreads();                                       // every wave is done reading before the next head's fill
   }
@@ -1534,32 +1401,14 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                               hipStream_t st) {
-  // variants kept selectable for same-box A/B runs (read per call, no cached state): lds (default) | t8 | w8
-  const char* e = getenv("DDP_GATHER");
-  const char mode = e ? e[0] : 'l';
+  constexpr int TH = 8, TW = 16;
+  const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+  const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
-  if (mode == 'l') {
-    // l (default) = 8 x 16 tiles, halo 3, 6 waves / SIMD; digits select the other compiled shapes (A/B runs)
-    const char v = e && e[1] ? e[1] : '0';
-    auto go = [&](auto kern, int TH, int TW) {
-      const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
-      const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
-      hipLaunchKernelGGL(kern, dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok, h, w, tiles_x, tiles_y,
-                         n_tiles);
-    };
-    if (v == '1') go(k_msda_gather_lds<8, 16, 3, 4>, 8, 16);
-    else if (v == '2') go(k_msda_gather_lds<4, 32, 3, 4>, 4, 32);
-    else if (v == '3') go(k_msda_gather_lds<8, 16, 2, 6>, 8, 16);
-    else if (v == '4') go(k_msda_gather_lds<8, 16, 4, 4>, 8, 16);
-    else go(k_msda_gather_lds<8, 16, 3, 6>, 8, 16);
-  } else if (mode == 't') {
-    hipLaunchKernelGGL(k_msda_gather_sb_pad_t8, dim3(cdiv(rows, 32)), dim3(256), 0, st, vpad, samp, out_sb, rows, n_tok, h, w);
-  } else {
-    hipLaunchKernelGGL(k_msda_gather_sb_pad, dim3(cdiv(rows, 32)), dim3(64 * GSB_WAVES), 0, st, vpad, samp, out_sb, rows, n_tok, h,
-                       w);
-  }
+  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4>), dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok,
+                     h, w, tiles_x, tiles_y, n_tiles);
   prof_end(TAG_GATHER, st);
-  return check_launch("k_msda_gather_sb_pad");
+  return check_launch("k_msda_gather_lds");
 }
 int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
                            int B, int N, float eps, hipStream_t st) {

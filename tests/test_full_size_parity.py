@@ -94,7 +94,7 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
     comparison (oracle taking its own decisions) is printed beside it; it is bounded loosely (1e-2) because one flipped
     near-tie moves its neighbourhood by up to ~bit_scale-sized changes of the noisy map (SURVEY.md §7 hard part 1)."""
     from oracle import ddp_oracle as O
-    tr = eng.x0_trace()[:, b:b + 1].long()                                   # (K, 1, h, w)
+    tr = eng.x0_trace()[:, b:b + 1].cpu().long()                             # (K, 1, h, w)
     trace = []
     ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.01, accumulation=accumulation,
                             trace=trace, x0_index=[tr[s] for s in range(K)])

@@ -481,9 +481,9 @@ def test_self_aligned_prepass_golden(dev, name):
     assert max_rel(logits.cpu(), g['logits']) < REL
     same = (logits.cpu().argmax(1) == g['logits'].argmax(1))
     assert same.float().mean() > 0.999
-    # x0 rows are exact table look-ups: identical wherever the argmax agrees
+    # x0 rows are table look-ups through sigmoid: equal to a few ulp of bit_scale wherever the argmax agrees
     diff = (preds.cpu() - g['preds']).abs().amax(1)
-    assert float(diff[same].max()) < 1e-8
+    assert float(diff[same].max()) < 1e-6 * cfg['bit_scale']
 
 
 @pytest.mark.gpu
