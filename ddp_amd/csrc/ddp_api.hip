@@ -97,6 +97,10 @@ struct Layout {
   float* bias_ext[DDP_MAX_LAYERS];                      //               fc1 bias | next value_proj bias | zeros
   unsigned char* pro_stream;                            // step prologue: W_m (8 wide) + layer 0's value / sampling proj (11 tall)
   float* pro_bias;                                      //                layer 0's value_proj bias at [1024, 1280)
+  float* ubuf;                                          // u = W_m . m_t, fp32 fragment-major (fused seg tails)
+  float* tlut;                                          // (Kc + 1, 256) = W_m . LUT^T
+  unsigned char* tail4_stream;                          // fused tail: conv_seg images + layer 0's 11 projection images
+  float* tail4_bias;                                    //             conv_seg bias | layer 0's value_proj bias at [1024, 1280)
   unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
   float* tail_bias;                                     //           conv_seg bias, zero padded
   size_t total;
@@ -258,6 +262,11 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
     o->pro_stream = reinterpret_cast<unsigned char*>(cv.take(b3_prologue_stream_bytes() / sizeof(float)));
     o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
+    const bool segp = c->task == DDP_TASK_SEG;
+    o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
+    o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
+    o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : 0);
+    o->ubuf = cv.take(segp ? (o->M + 255) / 256 * 256 * 256 : 0);
     o->q_sb = takesb(o->M, 256);
     o->q1_sb = takesb(o->M, 256);
     o->s_sb = takesb(o->M, 256);
@@ -276,6 +285,10 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->tail_bias = nullptr;
     o->pro_stream = nullptr;
     o->pro_bias = nullptr;
+    o->tail4_stream = nullptr;
+    o->tail4_bias = nullptr;
+    o->tlut = nullptr;
+    o->ubuf = nullptr;
   }
   o->total = cv.off * sizeof(float);
 }
@@ -395,6 +408,23 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
         set_error("tail bias copy failed");
         return DDP_E_LAUNCH;
       }
+    }
+    if (c->task == DDP_TASK_SEG) {      // fused tail (k_layer MODE 4): [conv_seg: 2 tall per 64 classes][layer 0's Wv: 8 tall][Wcat: 2 tall + 1 split-K]
+      const int nch = (o.Kc + 63) / 64;
+      DDP_TRY(launch_build_stages(o.wp_head.p, o.wp_head.comp_stride, 256, o.Kc, 1, nch, 2, 0, 0, 1, 2, o.tail4_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_v[0].p, o.wp_v[0].comp_stride, 256, 256, 1, 4, 2, 2 * nch, 0, 1, 2, o.tail4_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 1, 1, 2, 2 * nch + 8, 0, 1, 2, o.tail4_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 2, 1, 1, 2 * nch + 10, 64, 0, 0, o.tail4_stream, st));
+      if (hipMemsetAsync(o.tail4_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          (w->head_b && hipMemcpyAsync(o.tail4_bias, w->head_b, size_t(o.Kc) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) ||
+          hipMemcpyAsync(o.tail4_bias + DDP_FFN, w->layers[0].value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+              hipSuccess) {
+        set_error("fused tail bias copy failed");
+        return DDP_E_LAUNCH;
+      }
+      // T = LUT . W_m^T: the noisy-map half of the concat-conv applied to each of the K + 1 possible x0 vectors (exact
+      // fp32 products: the f32-input MFMA GEMM)
+      DDP_TRY(launch_linear(o.lut, 256, false, o.wm, 256, nullptr, nullptr, 0, 0, 0, o.tlut, 256, o.Kc + 1, 256, 256, 0, st));
     }
     if (c->task != DDP_TASK_DEPTH) {    // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 2 tall + 1 split-K]
       DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.pro_stream, st));
@@ -660,6 +690,12 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // tasks whose concat-conv feeds the encoder directly (seg): the head of the step is one kernel with layer 0's projections
   const bool pro_fused = o.fused_pro && cfg->task == DDP_TASK_SEG && o.h == o.hh &&
                          o.w == o.wh;
+  // seg + DDIM with both fusions on: the noisy map enters the loop only through u = W_m . m_t and its update is affine in
+  // (m_t, x0) with x0 one of K + 1 table rows, so steps 1 .. K-1 run NO concat-conv GEMM and keep no 256-channel map:
+  // the tail of step s updates u (u' = ua u + uc (W_m . LUT)[argmax]) and is at the same time the head of step s + 1
+  // (q = W_x x + b + u', layer 0's projections): k_layer MODE 4.  Step 0 starts from the noise with the step-prologue
+  // kernel, the last step's tail has nothing to update.
+  const bool u_chain = seg_tail && pro_fused;
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
@@ -678,6 +714,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
                                 256, 0, st));
         DDP_TRY(launch_bev_resample(o.feat0, o.s, o.R, geom, st));
         DDP_TRY(publish_q(o, o.s, st));
+      } else if (u_chain && s > 0) {
+        // the previous step's fused tail already wrote q (SB) and layer 0's value map / sampling table
       } else if (o.b3 && pro_fused) {
         // q = W_m m_t + xproj -> SB, layer 0's value / sampling projections: one persistent kernel
         PrologueLaunch pl;
@@ -687,6 +725,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         pl.bias_ext = o.pro_bias;
         pl.res = o.xproj;
         pl.res_rn = o.r > 1 ? o.r * o.N : 0;
+        pl.ubuf = u_chain && o.K > 1 ? o.ubuf : nullptr;
         pl.M = M0;
         pl.v_out = o.vpad;
         pl.samp_out = o.samp;
@@ -713,7 +752,22 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       // accumulation: softmax summed over the steps; otherwise the last step's scores are the output
       tl.prob = cfg->accumulation ? o.prob : o.logits;
       tl.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : (s == o.K - 1 ? 3 : 0);
-      tl.mask_sb = o.in_sb;
+      tl.mask_sb = u_chain ? nullptr : o.in_sb;
+      tl.fuse_next = u_chain && s + 1 < o.K;
+      if (tl.fuse_next) {
+        tl.stream = o.tail4_stream;
+        tl.bias_ext = o.tail4_bias;
+        tl.ubuf = o.ubuf;
+        tl.tlut = o.tlut;
+        tl.res = o.xproj;
+        tl.res_rn = o.r > 1 ? o.r * o.N : 0;
+        tl.v_out = o.vpad;
+        tl.samp_out = o.samp;
+        tl.py = o.py[0];
+        tl.px = o.px[0];
+        tl.n_tok = o.Nh;
+        tl.w = o.wh;
+      }
       tl.x0_idx = (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
       tl.M = M;
       tl.num_classes = o.Kc;

@@ -192,14 +192,14 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   return check_launch("b3::k_layer");
 }
 namespace {
-template <int NCH>
+template <int MODE, int NCH>
 int launch_tail_t(const b3::LayerArgs& la, int grid, hipStream_t st) {
   static LdsAttrOnce attr;
-  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, 1, NCH>), int(b3::LYR_LDS_B));
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, MODE, NCH>), int(b3::LYR_LDS_B));
   prof_begin(TAG_HEAD, st);
-  hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, 1, NCH>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, MODE, NCH>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
   prof_end(TAG_HEAD, st);
-  return check_launch("b3::k_layer (seg tail)");
+  return check_launch(MODE == 4 ? "b3::k_layer (seg tail + next step head)" : "b3::k_layer (seg tail)");
 }
 }  // namespace
 
@@ -226,11 +226,35 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;
   const int nch = (a.num_classes + 63) / 64;
+  if (a.fuse_next) {
+    // u' = ua u + uc T[argmax]:  m' = alpha' x0 + sigma' (m - alpha x0) / max(sigma, 1e-8)  (ddp.py:238-239) under W_m
+    la.ua = a.sigma_next / (a.sigma > 1e-8f ? a.sigma : 1e-8f);
+    la.uc = a.alpha_next - a.alpha * la.ua;
+    la.ubuf = a.ubuf;
+    la.tlut = a.tlut;
+    la.res = a.res;
+    la.res_rn = a.res_rn;
+    la.has_next = 1;
+    la.v_out = a.v_out;
+    la.samp_out = a.samp_out;
+    la.py = a.py;
+    la.px = a.px;
+    la.n_tok = a.n_tok;
+    la.w = a.w;
+    la.mask_sb = nullptr;
+    switch (nch) {
+      case 1: return launch_tail_t<4, 1>(la, grid, st);
+      case 2: return launch_tail_t<4, 2>(la, grid, st);
+      case 3: return launch_tail_t<4, 3>(la, grid, st);
+      case 4: return launch_tail_t<4, 4>(la, grid, st);
+      default: set_error("seg tail: %d classes (1..256)", a.num_classes); return DDP_E_BADCFG;
+    }
+  }
   switch (nch) {
-    case 1: return launch_tail_t<1>(la, grid, st);
-    case 2: return launch_tail_t<2>(la, grid, st);
-    case 3: return launch_tail_t<3>(la, grid, st);
-    case 4: return launch_tail_t<4>(la, grid, st);
+    case 1: return launch_tail_t<1, 1>(la, grid, st);
+    case 2: return launch_tail_t<1, 2>(la, grid, st);
+    case 3: return launch_tail_t<1, 3>(la, grid, st);
+    case 4: return launch_tail_t<1, 4>(la, grid, st);
     default: set_error("seg tail: %d classes (1..256)", a.num_classes); return DDP_E_BADCFG;
   }
 }
@@ -245,6 +269,7 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st) {
   la.bias_ext = a.bias_ext;
   la.res = a.res;
   la.res_rn = a.res_rn;
+  la.ubuf = a.ubuf;
   la.M = a.M;
   la.has_next = 1;
   la.v_out = a.v_out;

@@ -107,6 +107,19 @@ struct TailLaunch {
   unsigned char* x0_idx;        // optional: argmax class per token (diagnostic trace)
   int M, num_classes, ldl, prob_mode;
   float alpha, sigma, alpha_next, sigma_next;
+  // fuse_next: this launch is also the head of the NEXT step (k_layer MODE 4): mask_sb = nullptr, the update runs on
+  // u = W_m . m (ubuf, in place) with the table tlut = W_m . LUT^T, then q_next = res[row] + u' -> Q (SB, in place) and
+  // layer 0's value / sampling projections.  `stream` = 2 * chunks conv_seg images + 11 projection images,
+  // `bias_ext` = conv_seg bias | zeros | layer 0's value_proj bias at [1024, 1280) | zeros.
+  int fuse_next;
+  float* ubuf;
+  const float* tlut;
+  const float* res;
+  int res_rn;
+  float* v_out;
+  float* samp_out;
+  const float *py, *px;
+  int n_tok, w;
 };
 int launch_b3_tail(const TailLaunch& a, hipStream_t st);
 // head of a step on the same machinery: q = W_m . m_t + xproj -> SB, then layer 0's value / sampling projections
@@ -117,6 +130,7 @@ struct PrologueLaunch {
   const float* bias_ext;           // zeros | value_proj bias at [1024, 1280) | zeros
   const float* res;                // xproj rows (W_x x + b)
   int res_rn;                      // r * N when r noisy maps share one x row block, else 0
+  float* ubuf;                     // optional out: u_0 = W_m . m_0 (fp32 fragment-major) for the fused tails that follow
   int M;
   float* v_out;                    // zero-padded value map
   float* samp_out;

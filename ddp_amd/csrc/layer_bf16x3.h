@@ -83,6 +83,13 @@ struct LayerArgs {
   // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
   const float* res;              // fp32 rows of 256 (the loop-invariant half of the concat-conv, bias included)
   int res_rn;                    // row(m) = res_rn ? (m / res_rn) * n_tok + m % n_tok : m   (r noisy maps share one x)
+  // MODE 4 (seg tail of step s fused with the head of step s + 1) / MODE 2 (u out): the noisy map only ever enters the
+  // loop through u_t = W_m . m_t, and the DDIM update is affine in (m_t, x0) with x0 one of K + 1 table rows, so
+  //   u_{t+1} = ua . u_t + uc . (W_m . LUT)[argmax],   ua = sigma' / max(sigma, 1e-8),  uc = alpha' - alpha . ua
+  // replaces both the update of the 256-channel map and the W_m GEMM of every step but the first (ddp.py:223-239)
+  float* ubuf;                   // u, fp32 fragment-major rows of 256 (gemm_f32.h layout): written by MODE 2, read + written by MODE 4
+  const float* tlut;             // (num_classes + 1, 256): W_m . LUT^T
+  float ua, uc;
 };
 
 // vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
@@ -264,7 +271,8 @@ k_layer(LayerArgs la) {
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
   unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
+  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
+                                                                                    : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
   unsigned mb = 0;                                             // ring-slot LDS base (+ this wave's share)
@@ -480,7 +488,7 @@ k_layer(LayerArgs la) {
     const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
     char* qs = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
 
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 4) {
       // ---- seg tail: q fragments of this tile (the layer output), scores = conv_seg(q), per-token update
 #pragma unroll
       for (int b = 0; b < 16; ++b)
@@ -585,6 +593,48 @@ k_layer(LayerArgs la) {
                 *reinterpret_cast<f32x4*>(pr + cls0) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
             }
       }
+      if constexpr (MODE == 4) {
+        // ---- the update in terms of u = W_m . m (see LayerArgs), then the NEXT step's q = (W_x x + b) + u' -> SB + fragments:
+        // per quarter of the row 8 + 8 + 8 loads (u, table row of the argmax class, x projection row) in flight
+        const float* trow = la.tlut + size_t(bi) * 256 + 4 * h;
+        float* ub = la.ubuf + grp * 8192 + lane * 4;
+        int mr = m < M ? m : M - 1;
+        const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
+        const float* rp = la.res + row * 256 + 4 * h;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          f32x4 uu[2][4], tt[2][4], xx[2][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int t = qt * 2 + i;
+              uu[i][g] = *reinterpret_cast<const f32x4*>(ub + t * 1024 + g * 256);
+              tt[i][g] = *reinterpret_cast<const f32x4*>(trow + t * 32 + 8 * g);
+              xx[i][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
+            }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int t = qt * 2 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) uu[i][g][e] = la.ua * uu[i][g][e] + la.uc * tt[i][g][e];
+              *reinterpret_cast<f32x4*>(ub + t * 1024 + g * 256) = uu[i][g];
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const int b = 2 * t + gp;
+              float xv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3] + uu[i][2 * gp + (e >> 2)][e & 3];
+              split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+            }
+          }
+        }
+      } else if (la.mask_sb) {
       // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out - two batches of eight K16 blocks:
       // 24 + 16 loads in flight, then eight compute / store rounds (all 16 blocks at once need 320 architectural VGPRs)
       {
@@ -621,8 +671,10 @@ k_layer(LayerArgs la) {
           }
         }
       }
+      }   // la.mask_sb
     }
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
+    if constexpr (MODE != 4) {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
 #pragma unroll
@@ -715,6 +767,14 @@ k_layer(LayerArgs la) {
       }
       p0_stage(6, I0);
       p0_stage(7, I1);
+      if (la.ubuf) {       // u_0 = W_m . m_0 for the u recursion of the following steps (MODE 4)
+        float* ub = la.ubuf + grp * 8192 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(ub + t * 1024 + g * 256) = f32x4{acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+      }
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -946,9 +1006,10 @@ k_layer(LayerArgs la) {
     }
 
     }   // MODE == 0
+    }   // MODE != 4
     refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
-    if (MODE == 2 || la.has_next) {
+    if (MODE == 2 || MODE == 4 || la.has_next) {
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;
