@@ -426,8 +426,10 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
       // fp32 products: the f32-input MFMA GEMM)
       DDP_TRY(launch_linear(o.lut, 256, false, o.wm, 256, nullptr, nullptr, 0, 0, 0, o.tlut, 256, o.Kc + 1, 256, 256, 0, st));
     }
-    if (c->task != DDP_TASK_DEPTH) {    // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 2 tall + 1 split-K]
-      DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.pro_stream, st));
+    {                                   // step prologue: [W_m: 8 wide stages][layer 0's Wv: 8 tall][layer 0's Wcat: 2 tall + 1 split-K]
+      // (depth has no W_m GEMM - one input channel - and uses images 8..18 only: k_layer MODE 3)
+      if (c->task != DDP_TASK_DEPTH)
+        DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.pro_stream, st));
       DDP_TRY(launch_build_stages(o.wp_v[0].p, o.wp_v[0].comp_stride, 256, 256, 1, 4, 2, 8, 0, 1, 2, o.pro_stream, st));
       DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 1, 1, 2, 16, 0, 1, 2, o.pro_stream, st));
       DDP_TRY(launch_build_stages(o.wp_cat[0].p, o.wp_cat[0].comp_stride, 256, 96, 2, 1, 1, 18, 64, 0, 0, o.pro_stream, st));
@@ -487,7 +489,28 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
     for (int l = 0; l < o.L; ++l) {
       const ddp_layer_weights& lw = w->layers[l];
       // later layers: emitted by the previous layer kernel; layer 0: by the step prologue kernel when that ran
-      const bool own_proj = !fused || (l == 0 && !l0_projected);
+      bool own_proj = !fused || (l == 0 && !l0_projected);
+      if (own_proj && fused) {
+        // layer 0 of a path without a fused step head (bev after its grid resampling, ddp_head_forward): the value /
+        // sampling projections of the SB q as ONE launch of the layer kernel's P3 (k_layer MODE 3), padded value map out
+        L0ProjLaunch pj;
+        pj.Q = o.q_sb;
+        pj.stream = o.pro_stream + size_t(8) * 48 * 1024;
+        pj.bias_ext = o.pro_bias;
+        pj.res = nullptr;
+        pj.res_rn = 0;
+        pj.wm = nullptr;
+        pj.dvec = nullptr;
+        pj.M = M;
+        pj.v_out = o.vpad;
+        pj.samp_out = o.samp;
+        pj.py = o.py[0];
+        pj.px = o.px[0];
+        pj.n_tok = o.Nh;
+        pj.w = o.wh;
+        DDP_TRY(launch_b3_l0proj(pj, st));
+        own_proj = false;
+      }
       if (own_proj) {
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_v[l], lw.value_proj_b, nullptr, 0, 0, 0, o.v, 256, M, 256, 256, st, TAG_VALUE));
         DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
@@ -700,7 +723,28 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
     // feat = transform(cat[x, mask_t])
-    if (cfg->task == DDP_TASK_DEPTH) {
+    bool depth_head = false;
+    if (cfg->task == DDP_TASK_DEPTH && o.fused_pro) {
+      // down conv over cat[x, depth_t] (depther/ddp.py:236-237) = hoisted x half + ONE depth column: q is formed inside
+      // the layer-0 projection kernel (k_layer MODE 3): no feat / SB-conversion / VALUE / SAMP launches
+      L0ProjLaunch pj;
+      pj.Q = o.q_sb;
+      pj.stream = o.pro_stream + size_t(8) * 48 * 1024;
+      pj.bias_ext = o.pro_bias;
+      pj.res = o.xproj;
+      pj.res_rn = o.r > 1 ? o.r * o.N : 0;
+      pj.wm = o.wm;
+      pj.dvec = o.mask;
+      pj.M = M0;
+      pj.v_out = o.vpad;
+      pj.samp_out = o.samp;
+      pj.py = o.py[0];
+      pj.px = o.px[0];
+      pj.n_tok = o.Nh;
+      pj.w = o.wh;
+      DDP_TRY(launch_b3_l0proj(pj, st));
+      depth_head = true;
+    } else if (cfg->task == DDP_TASK_DEPTH) {
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.s, o.B, o.r, o.N, st));
       DDP_TRY(publish_q(o, o.s, st));
     } else {
@@ -742,7 +786,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
                                   st));
       }
     }
-    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused));
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head));
     if (seg_tail) {
       TailLaunch tl;
       tl.Q = o.q_sb;

@@ -289,6 +289,36 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st) {
   return check_launch("b3::k_layer (step prologue)");
 }
 
+int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st) {
+  if (a.M <= 0) return DDP_OK;
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  la.Q = a.Q;
+  la.stream = a.stream;
+  la.bias_ext = a.bias_ext;
+  la.res = a.res;
+  la.res_rn = a.res_rn;
+  la.bo = a.wm;
+  la.dvec = a.dvec;
+  la.M = a.M;
+  la.has_next = 1;
+  la.v_out = a.v_out;
+  la.samp_out = a.samp_out;
+  la.py = a.py;
+  la.px = a.px;
+  la.n_tok = a.n_tok;
+  la.w = a.w;
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_VALUE, 3>), int(b3::LYR_LDS_B));
+  const int n_cu = cu_count();
+  const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  prof_begin(TAG_VALUE, st);
+  hipLaunchKernelGGL((b3::k_layer<TAG_VALUE, 3>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  prof_end(TAG_VALUE, st);
+  return check_launch("b3::k_layer (layer 0 projections)");
+}
+
 size_t b3_prologue_stream_bytes() { return size_t(b3::LYR_ST_OUT + b3::LYR_ST_NEXT) * b3::LYR_STAGE_B; }
 size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }
 int b3_layer_bias_floats() { return b3::LYR_BIAS_N; }

@@ -138,6 +138,23 @@ struct PrologueLaunch {
   int n_tok, w;
 };
 int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
+// layer 0's value / sampling projections alone (k_layer MODE 3): q given as SB (res == nullptr), or formed as the depth
+// concat-conv q = res[row] + wm * dvec[m] and written to Q.  stream = the 11 projection images, bias_ext as PrologueLaunch.
+struct L0ProjLaunch {
+  unsigned short* Q;
+  const unsigned char* stream;
+  const float* bias_ext;
+  const float* res;
+  int res_rn;
+  const float* wm;                 // (256) depth column of the concat-conv, with res
+  const float* dvec;               // (M)
+  int M;
+  float* v_out;
+  float* samp_out;
+  const float *py, *px;
+  int n_tok, w;
+};
+int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st);
 size_t b3_prologue_stream_bytes();
 size_t b3_layer_stream_bytes();
 int b3_layer_bias_floats();

@@ -90,6 +90,10 @@ struct LayerArgs {
   float* ubuf;                   // u, fp32 fragment-major rows of 256 (gemm_f32.h layout): written by MODE 2, read + written by MODE 4
   const float* tlut;             // (num_classes + 1, 256): W_m . LUT^T
   float ua, uc;
+  // MODE 3 (layer 0's projections for the tasks without a fused step head): q comes as SB (Q, res == nullptr: bev after
+  // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
+  // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
+  const float* dvec;             // (M) noisy depth map
 };
 
 // vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
@@ -271,7 +275,7 @@ k_layer(LayerArgs la) {
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
   unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
+  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
                                                                                     : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
@@ -371,6 +375,7 @@ k_layer(LayerArgs la) {
   {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + LYR_BIAS_OFF);
     for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
+    if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
     if constexpr (MODE == 0) {
       tab[LYR_T_BO + tid] = la.bo[tid];
       tab[LYR_T_GA0 + tid] = la.ga0[tid];
@@ -673,8 +678,51 @@ k_layer(LayerArgs la) {
       }
       }   // la.mask_sb
     }
-    if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
-    if constexpr (MODE != 4) {
+    if constexpr (MODE == 3) {
+      if (la.res) {
+        // depth step head: q = (W_x x + b)[row] + w_d * d  -> SB + fragments (no GEMM: the noisy map has one channel)
+        int mr = m_base + j;
+        mr = mr < M ? mr : M - 1;
+        const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
+        const float* rp = la.res + row * 256 + 4 * h;
+        const float dv = la.dvec[mr];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          f32x4 xx[2][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xx[i][g] = *reinterpret_cast<const f32x4*>(rp + (qt * 2 + i) * 32 + 8 * g);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int t = qt * 2 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 wd = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xx[i][g][e] = xx[i][g][e] + wd[e] * dv;
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const int b = 2 * t + gp;
+              float xv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3];
+              split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+      }
+    }
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) {
+    if constexpr (MODE != 4 && MODE != 3) {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
 #pragma unroll
@@ -1006,10 +1054,10 @@ k_layer(LayerArgs la) {
     }
 
     }   // MODE == 0
-    }   // MODE != 4
+    }   // MODE 0 / 2 only
     refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
-    if (MODE == 2 || MODE == 4 || la.has_next) {
+    if (MODE == 2 || MODE == 3 || MODE == 4 || la.has_next) {
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;
