@@ -159,6 +159,15 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
   return launch_b3<3, TAG_SAMP>(ga, e, st);
 }
 
+#ifdef DDP_LYR_STAMP
+// debug builds only (not declared in include/ddp_mi355x.h, not part of the product library): where the layer kernel's
+// cycle stamps go - scripts/stamp_layer.py
+static unsigned long long* g_lyr_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void ddp_debug_set_layer_stamps(void* d_buf) {
+  g_lyr_stamps = static_cast<unsigned long long*>(d_buf);
+}
+#endif
+
 int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   if (a.M <= 0) return DDP_OK;
   b3::LayerArgs la;
@@ -181,6 +190,9 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   la.px = a.px;
   la.n_tok = a.n_tok;
   la.w = a.w;
+#ifdef DDP_LYR_STAMP
+  la.stamps = g_lyr_stamps;
+#endif
   static LdsAttrOnce attr;
   attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN>), int(b3::LYR_LDS_B));
   const int n_cu = cu_count();

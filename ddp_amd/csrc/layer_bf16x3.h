@@ -94,6 +94,7 @@ struct LayerArgs {
   // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
   // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
   const float* dvec;             // (M) noisy depth map
+  unsigned long long* stamps;    // -DDDP_LYR_STAMP builds only (scripts/stamp_layer.py): per (block, wave) cycle sums of the phases
 };
 
 // vmcnt(12): everything but the 12 newest vector-memory ops (= the DMA pieces of the stage just issued) is done
@@ -255,6 +256,23 @@ __device__ __forceinline__ void stream_piece(unsigned long long base, unsigned v
 // MODE 2: the head of a step: q = W_m . m_t + (W_x x + b) (the noisy-map half of the concat-conv, ddp.py:223-224;
 //         8 wide stages + the loop-invariant fp32 rows), q -> SB, then layer 0's value / sampling projections from the
 //         q fragments still in registers (P3).  Replaces the FEAT / VALUE / SAMP GEMM launches of every step.
+// Cycle accounting (debug builds, -DDDP_LYR_STAMP): s_memtime at the phase boundaries of the MODE 0 tile loop, deltas summed
+// per phase in SGPRs (uniform values, constant indices) and added to a buffer once per wave at kernel exit.  Not compiled
+// into the product library.
+#ifdef DDP_LYR_STAMP
+constexpr int LYR_NSTAMP = 10;
+#define DDP_LYR_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[LYR_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DDP_LYR_STAMP_AT(i)                                   \
+  {                                                           \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                            \
+    st_prev = st_now;                                         \
+  }
+#else
+#define DDP_LYR_STAMP_DECL
+#define DDP_LYR_STAMP_AT(i)
+#endif
+
 template <int TAG, int MODE = 0, int NCH = 0>
 __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
@@ -484,7 +502,9 @@ k_layer(LayerArgs la) {
       }
   };
 
+  DDP_LYR_STAMP_DECL
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    DDP_LYR_STAMP_AT(9)                                        // tile turnaround (and the kernel prologue)
     const size_t grp = size_t(tile) * (LYR_BM / 32) + wave;    // this wave's 32-token group
     // opaque per tile: otherwise the (tile-invariant) reads of the per-channel table are hoisted out of the tile
     // loop - ~800 values per lane - and spilled to scratch
@@ -851,6 +871,7 @@ k_layer(LayerArgs la) {
       for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
     p0_stage(7, I1);
 
+    DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages
     // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)
     {
       float sum = 0.f;
@@ -900,12 +921,14 @@ k_layer(LayerArgs la) {
       }
     }
 
+    DDP_LYR_STAMP_AT(1)                                        // P1: residual + LayerNorm0 + split
     refresh();
     // ---- P2: FFN, 64 hidden channels at a time: acc1 = b1 + W1[chunk] . x; h = GELU(acc1); acc2 += W2[:, chunk] . h
     for (int hc = 0; hc < 16; ++hc) {
       f32x16 acc1[2];
       bias_init(acc1, hc);
       tall_pair(acc1[0], acc1[1]);
+      DDP_LYR_STAMP_AT(2)                                      // fc1 stage pairs
       // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2)).
       // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: four elements per pair of
       // blocks, 4 x 18 single instructions + 6 packs handed out slot by slot (GELU_SCHED).
@@ -916,6 +939,7 @@ k_layer(LayerArgs la) {
         for (int e = 0; e < 8; ++e) xg[e] = acc1[0][e];
         gelu_split8_packed(xg, hcur[0], hcur[1], hcur[2]);
       }
+      DDP_LYR_STAMP_AT(3)                                      // exposed GELU of k-block 0
       // (EXPERIMENT: early hand-over between the two wide stages, see tall_pair)
       u32x4 w[2][3];
 #pragma unroll
@@ -996,6 +1020,7 @@ k_layer(LayerArgs la) {
         }
         slot = nxt(slot);
       }
+      DDP_LYR_STAMP_AT(4)                                      // fc2 stage pairs (GELU of k-blocks 1..3 in the filler slots)
     }
 
     refresh();
@@ -1053,6 +1078,7 @@ k_layer(LayerArgs la) {
       }
     }
 
+    DDP_LYR_STAMP_AT(5)                                        // LayerNorm1 + FiLM + split + q' stores
     }   // MODE == 0
     }   // MODE 0 / 2 only
     refresh();
@@ -1085,6 +1111,7 @@ k_layer(LayerArgs la) {
               *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]};
         }
       }
+      DDP_LYR_STAMP_AT(6)                                      // next value_proj (8 stages + stores)
 #pragma unroll
       for (int sc2 = 0; sc2 < 2; ++sc2) {
         f32x16 a[2];
@@ -1135,9 +1162,14 @@ k_layer(LayerArgs la) {
           }
         }
       }
+      DDP_LYR_STAMP_AT(7)                                      // next sampling projection (3 stages + epilogues)
     }
     }
   }
+#ifdef DDP_LYR_STAMP
+  if (la.stamps && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < LYR_NSTAMP; ++i) la.stamps[(size_t(blockIdx.x) * 4 + wave) * LYR_NSTAMP + i] += st_acc[i];   // summed over launches
+#endif
 #undef DDP_LYR_BLOCK
 #undef DDP_LYR_BLOCK2
 #undef DDP_LYR_K
