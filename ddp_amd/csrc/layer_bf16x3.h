@@ -260,8 +260,8 @@ __device__ __forceinline__ void stream_piece(unsigned long long base, unsigned v
 // per phase in SGPRs (uniform values, constant indices) and added to a buffer once per wave at kernel exit.  Not compiled
 // into the product library.
 #ifdef DDP_LYR_STAMP
-constexpr int LYR_NSTAMP = 10;
-#define DDP_LYR_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[LYR_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+constexpr int LYR_NSTAMP = 16;
+#define DDP_LYR_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[LYR_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DDP_LYR_STAMP_AT(i)                                   \
   {                                                           \
     const unsigned long long st_now = __builtin_readcyclecounter(); \
@@ -764,6 +764,7 @@ k_layer(LayerArgs la) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+    DDP_LYR_STAMP_AT(10)                                       // tile start: first fragments issued, bias in, weight fragments read
     auto p0_stage = [&](int st, auto lastc) __attribute__((always_inline)) {
       constexpr bool last = decltype(lastc)::value != 0;
       stage_begin(nxt(nxt(slot)));
@@ -819,7 +820,10 @@ k_layer(LayerArgs la) {
       }
       slot = nxt(slot);
     };
-    for (int st = 0; st < 6; ++st) p0_stage(st, I0);
+    p0_stage(0, I0);
+    DDP_LYR_STAMP_AT(11)                                       // stage 0 (waits for the tile's first fragments)
+    for (int st = 1; st < 6; ++st) p0_stage(st, I0);
+    DDP_LYR_STAMP_AT(12)                                       // stages 1..5
     if constexpr (MODE == 2) {
       // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
       f32x4 xr[8][4];
@@ -865,6 +869,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
     p0_stage(6, I0);
+    DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
 #pragma unroll
     for (int b = 8; b < 16; ++b)
 #pragma unroll

@@ -23,14 +23,16 @@ from ddp_amd.engine import DDPEngine  # noqa: E402
 from ddp_amd.utils import synthetic  # noqa: E402
 import bench  # noqa: E402
 
-PHASES = ['P0 output_proj (8 stages)', 'P1 residual + LN0 + split', 'fc1 (32 stages)', 'GELU k-block 0 (16x, exposed)',
+PHASES = ['P0 rest (second residual fetch + stage 7)', 'P1 residual + LN0 + split', 'fc1 (32 stages)', 'GELU k-block 0 (16x, exposed)',
           'fc2 (32 stages, GELU fillers)', 'LN1 + FiLM + split + q stores', 'P3 value_proj (8 stages + stores)',
-          'P3 sampling proj (3 stages + epilogues)', '-', 'tile turnaround / kernel prologue']
-MFMAS = [768, 0, 3072, 0, 3072, 0, 768, 288, 0, 0]          # per wave and tile
+          'P3 sampling proj (3 stages + epilogues)', '-', 'tile turnaround / kernel prologue',
+          'P0a tile start (issue first fragments, bias, weight frags)', 'P0b stage 0', 'P0c stages 1-5', 'P0d residual fetch + stage 6',
+          '-', '-']
+MFMAS = [96, 0, 3072, 0, 3072, 0, 768, 288, 0, 0, 0, 96, 480, 96, 0, 0]          # per wave and tile (slot 0 = what is left of P0: stage 7)
 
 
 def main():
-    path = os.path.join(ROOT, 'ddp_amd', 'lib_stamp', 'libddp_mi355x.so')
+    path = os.path.join(ROOT, 'ddp_amd', sys.argv[1] if len(sys.argv) > 1 else 'lib_stamp', 'libddp_mi355x.so')
     lib = _lib.load(path)
     lib.ddp_debug_set_layer_stamps.argtypes = [C.c_void_p]
     lib.ddp_debug_set_layer_stamps.restype = None
@@ -44,14 +46,14 @@ def main():
     eng.sample(dx, dn)
     torch.cuda.synchronize()
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    buf = torch.zeros(n_cu * 4 * 10, dtype=torch.int64, device=dev)
+    buf = torch.zeros(n_cu * 4 * 16, dtype=torch.int64, device=dev)
     lib.ddp_debug_set_layer_stamps(buf.data_ptr())
     eng.sample(dx, dn)              # one step = 6 layer launches, summed in the buffer (5 of them project for a next layer)
     torch.cuda.synchronize()
     lib.ddp_debug_set_layer_stamps(None)
-    st = buf.cpu().view(n_cu * 4, 10).double()
+    st = buf.cpu().view(n_cu * 4, 16).double()
     tiles = (wl['batch'] * wl['h'] * wl['w'] + 127) // 128 / n_cu
-    launches = torch.tensor([6, 6, 6, 6, 6, 6, 5, 5, 1, 6], dtype=torch.float64)
+    launches = torch.tensor([6, 6, 6, 6, 6, 6, 5, 5, 1, 6, 6, 6, 6, 6, 1, 1], dtype=torch.float64)
     per_tile = st.mean(0) / tiles / launches
     tot = float(per_tile.sum())
     out = {'tiles_per_cu': tiles, 'cycles_per_tile': round(tot), 'note': 'mean over the 6 layer launches of one step (P3 over the 5 that have a next layer)', 'phases': {}}
