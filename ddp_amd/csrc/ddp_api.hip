@@ -475,12 +475,13 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
 
 // publish a row-major (M,256) activation as the encoder input: fp32 fragment-major q, or SB in bf16x3 mode
 int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
-  if (o.b3) return launch_row_to_sb(row_major, 256, o.q_sb, int(o.M), 256, st);
-  return launch_row_to_blk(row_major, o.q, int(o.M), st);
+  if (o.b3 && !o.fused_layer) return launch_row_to_sb(row_major, 256, o.q_sb, int(o.M), 256, st);
+  return launch_row_to_blk(row_major, o.q, int(o.M), st);     // the layer kernels (and the fp32 engine) take q as fp32 fragments
 }
 
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
-int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st, bool l0_projected = false) {
+int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st, bool l0_projected = false,
+                    bool sb_out = true) {
   const int M = int(o.M);
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
@@ -494,7 +495,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         // layer 0 of a path without a fused step head (bev after its grid resampling, ddp_head_forward): the value /
         // sampling projections of the SB q as ONE launch of the layer kernel's P3 (k_layer MODE 3), padded value map out
         L0ProjLaunch pj;
-        pj.Q = o.q_sb;
+        pj.Q = o.q;
         pj.stream = o.pro_stream + size_t(8) * 48 * 1024;
         pj.bias_ext = o.pro_bias;
         pj.res = nullptr;
@@ -523,7 +524,8 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         // output_proj + LN0 + FFN + LN1 + FiLM + the next layer's value / sampling projections: one persistent kernel
         LayerLaunch ll;
         ll.S = o.s_sb;
-        ll.Q = o.q_sb;
+        ll.Q = o.q;
+        ll.Q_sb = (sb_out && l + 1 == o.L) ? o.q_sb : nullptr;      // a head GEMM after the encoder reads SB
         ll.stream = o.wstream[l];
         ll.bias_ext = o.bias_ext[l];
         ll.bo = lw.output_proj_b;
@@ -728,7 +730,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       // down conv over cat[x, depth_t] (depther/ddp.py:236-237) = hoisted x half + ONE depth column: q is formed inside
       // the layer-0 projection kernel (k_layer MODE 3): no feat / SB-conversion / VALUE / SAMP launches
       L0ProjLaunch pj;
-      pj.Q = o.q_sb;
+      pj.Q = o.q;
       pj.stream = o.pro_stream + size_t(8) * 48 * 1024;
       pj.bias_ext = o.pro_bias;
       pj.res = o.xproj;
@@ -764,7 +766,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         // q = W_m m_t + xproj -> SB, layer 0's value / sampling projections: one persistent kernel
         PrologueLaunch pl;
         pl.mask_sb = o.in_sb;
-        pl.Q = o.q_sb;
+        pl.Q = o.q;
         pl.stream = o.pro_stream;
         pl.bias_ext = o.pro_bias;
         pl.res = o.xproj;
@@ -779,17 +781,18 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         pl.w = o.wh;
         DDP_TRY(launch_b3_prologue(pl, st));
       } else if (o.b3) {
-        DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, nullptr, M0, 256, 256, 0, st,
-                                    TAG_FEAT));
+        // separate concat-conv GEMM: SB for the tile-GEMM layers, and fp32 fragments for the layer kernels
+        DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, o.fused_layer ? o.q : nullptr, M0,
+                                    256, 256, 0, st, TAG_FEAT));
       } else {
         DDP_TRY(launch_linear_blk(o.mask, 256, false, o.wm, 256, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q, M0, 256, 256, 0,
                                   st));
       }
     }
-    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head));
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !seg_tail));
     if (seg_tail) {
       TailLaunch tl;
-      tl.Q = o.q_sb;
+      tl.Q = o.q;
       tl.stream = o.tail_stream;
       tl.bias_ext = o.tail_bias;
       tl.lut = o.lut;

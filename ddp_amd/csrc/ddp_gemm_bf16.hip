@@ -174,6 +174,7 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   memset(&la, 0, sizeof(la));
   la.S = a.S;
   la.Q = a.Q;
+  la.Q_sb = a.Q_sb;
   la.stream = a.stream;
   la.bias_ext = a.bias_ext;
   la.bo = a.bo;
@@ -219,7 +220,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   if (a.M <= 0) return DDP_OK;
   b3::LayerArgs la;
   memset(&la, 0, sizeof(la));
-  la.Q = const_cast<unsigned short*>(a.Q);
+  la.Q = a.Q;
   la.stream = a.stream;
   la.bias_ext = a.bias_ext;
   la.M = a.M;

@@ -85,7 +85,8 @@ int launch_build_stages(const unsigned short* Wp, size_t comp_stride, int K, int
                         int base, int a, int b, int c, unsigned char* stream, hipStream_t st);
 struct LayerLaunch {
   const unsigned short* S;
-  unsigned short* Q;
+  float* Q;                 // fp32 fragment-major rows of 256 (residual in, layer output out, in place)
+  unsigned short* Q_sb;     // optional: the output also as SB (a tile GEMM consumes it)
   const unsigned char* stream;
   const float* bias_ext;
   const float *bo, *ga0, *be0, *b2, *ga1, *be1;
@@ -98,7 +99,7 @@ struct LayerLaunch {
 int launch_b3_layer(const LayerLaunch& a, hipStream_t st);
 // seg tail on the layer kernel's machinery: conv_seg + argmax + softmax accumulation + x0 LUT + DDIM update (SB in / out)
 struct TailLaunch {
-  const unsigned short* Q;      // SB decoder output
+  float* Q;                     // fp32 fragment-major decoder output (fuse_next: replaced by the next step's q)
   const unsigned char* stream;  // 2 * chunks stage images of conv_seg (64 classes per chunk)
   const float* bias_ext;        // conv_seg bias, zero padded to b3_layer_bias_floats()
   const float* lut;
@@ -125,7 +126,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st);
 // head of a step on the same machinery: q = W_m . m_t + xproj -> SB, then layer 0's value / sampling projections
 struct PrologueLaunch {
   const unsigned short* mask_sb;   // SB noisy map (A operand)
-  unsigned short* Q;               // SB q out
+  float* Q;                        // fp32 fragment-major q out
   const unsigned char* stream;     // 8 wide stages of W_m + 8 + 3 tall stages of layer 0's value_proj / sampling projection
   const float* bias_ext;           // zeros | value_proj bias at [1024, 1280) | zeros
   const float* res;                // xproj rows (W_x x + b)
@@ -141,7 +142,7 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
 // layer 0's value / sampling projections alone (k_layer MODE 3): q given as SB (res == nullptr), or formed as the depth
 // concat-conv q = res[row] + wm * dvec[m] and written to Q.  stream = the 11 projection images, bias_ext as PrologueLaunch.
 struct L0ProjLaunch {
-  unsigned short* Q;
+  float* Q;                        // fp32 fragment-major q (in; out when formed here)
   const unsigned char* stream;
   const float* bias_ext;
   const float* res;

@@ -57,7 +57,10 @@ constexpr int LYR_STAGES = LYR_ST_OUT + LYR_ST_FFN + LYR_ST_NEXT;
 
 struct LayerArgs {
   const unsigned short* S;       // SB attention output (A operand of output_proj)
-  unsigned short* Q;             // SB layer input (residual) -> layer output, in place (a block touches only its tokens)
+  float* Q;                      // layer input (residual) -> layer output, in place (a block touches only its tokens): fp32 in the
+                                 // accumulator layout (fragment-major, gemm_f32.h): [32-token group][tile t][quad g][lane][4] - 4 B per
+                                 // element instead of the 6 B of SB; whoever needs it as an MFMA operand splits it after the load
+  unsigned short* Q_sb;          // optional: the layer output ALSO as SB (a tile GEMM follows: head conv of depth / bev / ddpm)
   const unsigned char* stream;   // LYR_STAGES stage images
   const float* bias_ext;         // (LYR_BIAS_N)
   const float* bo;               // output_proj bias (256)
@@ -502,6 +505,34 @@ k_layer(LayerArgs la) {
       }
   };
 
+  // q (fp32 accumulator layout) -> the 16 x 3 B fragments of a contraction over its 256 channels: K16 block b = 2t + gp is
+  // the quad pair (2gp, 2gp + 1) of tile t
+  auto load_q_fragments = [&](const float* qp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 qv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) qv[i][g] = *reinterpret_cast<const f32x4*>(qp + (half * 4 + i) * 1024 + g * 256);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int b = 2 * (half * 4 + i) + gp;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = qv[i][2 * gp + (e >> 2)][e & 3];
+          split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+        }
+    }
+  };
+  // eight values of K16 block b (as produced for split8) -> q in HBM
+  auto store_q_block = [&](float* qp, int b, const float (&xv)[8]) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(qp + (b >> 1) * 1024 + (2 * (b & 1)) * 256) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+    *reinterpret_cast<f32x4*>(qp + (b >> 1) * 1024 + (2 * (b & 1) + 1) * 256) = f32x4{xv[4], xv[5], xv[6], xv[7]};
+  };
+
   DDP_LYR_STAMP_DECL
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     DDP_LYR_STAMP_AT(9)                                        // tile turnaround (and the kernel prologue)
@@ -511,14 +542,11 @@ k_layer(LayerArgs la) {
     refresh();
     const int m_base = tile * LYR_BM + wave * 32;
     const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
-    char* qs = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
+    float* qf = la.Q + grp * 8192 + lane * 4;                   // + t * 1024 + g * 256: this lane's accumulator quad (t, g)
 
     if constexpr (MODE == 1 || MODE == 4) {
       // ---- seg tail: q fragments of this tile (the layer output), scores = conv_seg(q), per-token update
-#pragma unroll
-      for (int b = 0; b < 16; ++b)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+      load_q_fragments(qf);
       f32x16 lg[NCH > 0 ? NCH : 1][2];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -654,8 +682,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3] + uu[i][2 * gp + (e >> 2)][e & 3];
               split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-#pragma unroll
-              for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+              store_q_block(qf, b, xv);
             }
           }
         }
@@ -729,16 +756,12 @@ k_layer(LayerArgs la) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3];
               split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-#pragma unroll
-              for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+              store_q_block(qf, b, xv);
             }
           }
         }
       } else {
-#pragma unroll
-        for (int b = 0; b < 16; ++b)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) xa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+        load_q_fragments(qf);
       }
     }
     if constexpr (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) {
@@ -856,24 +879,25 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e] + xr[t][2 * gp + (e >> 2)][e & 3];
           split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qs + (b * 3 + c) * 1024) = xa[b][c];
+          store_q_block(qf, b, xv);
         }
       }
     }
     if constexpr (MODE == 0) {
     // residual fragments: fetched under the last two stages
-    u32x4 qa[16][3];
+    // (fp32: 32 x 16 B per lane instead of 48 - the r02i stamps put most of P0's idle time on these two fetches: every CU
+    // asks for its residual rows in the same microseconds)
+    f32x4 qr[8][4];
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
     p0_stage(6, I0);
     DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
 #pragma unroll
-    for (int b = 8; b < 16; ++b)
+    for (int t = 4; t < 8; ++t)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) qa[b][c] = *reinterpret_cast<const u32x4*>(qs + (b * 3 + c) * 1024);
+      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
     p0_stage(7, I1);
 
     DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages
@@ -884,8 +908,7 @@ k_layer(LayerArgs la) {
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int b = 2 * t + (r >> 3), u = r & 7;
-          const float v = acc2[t][r] + ((bf_elem(qa[b][0], u) + bf_elem(qa[b][1], u)) + bf_elem(qa[b][2], u));
+          const float v = acc2[t][r] + qr[t][r >> 2][r & 3];
           acc2[t][r] = v;
           sum += v;
         }
@@ -1033,8 +1056,9 @@ k_layer(LayerArgs la) {
     {
       // fresh base (re-derived, not copied: qs would have to live - spilled - across the FFN): otherwise the 48 64-bit
       // addresses of the residual loads are kept for these stores
-      char* qst = reinterpret_cast<char*>(la.Q) + grp * 256 * 192 + lane * 16;
+      float* qst = la.Q + grp * 8192 + lane * 4;
       asm volatile("" : "+v"(qst));
+      char* qsb = reinterpret_cast<char*>(la.Q_sb) + grp * 256 * 192 + lane * 16;      // only dereferenced when la.Q_sb is set
       // nothing to hide behind here: two channels per instruction on the packed-fp32 path
       f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
@@ -1077,8 +1101,11 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
           split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+          store_q_block(qst, b, xv);
+          if (la.Q_sb) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qst + (b * 3 + c) * 1024) = xa[b][c];
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qsb + (b * 3 + c) * 1024) = xa[b][c];
+          }
         }
       }
     }
