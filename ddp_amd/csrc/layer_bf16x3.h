@@ -845,11 +845,9 @@ k_layer(LayerArgs la) {
     };
     p0_stage(0, I0);
     DDP_LYR_STAMP_AT(11)                                       // stage 0 (waits for the tile's first fragments)
-    for (int st = 1; st < 4; ++st) p0_stage(st, I0);
-    DDP_LYR_STAMP_AT(12)                                       // stages 1..3
+    for (int st = 1; st < 6; ++st) p0_stage(st, I0);
+    DDP_LYR_STAMP_AT(12)                                       // stages 1..5
     if constexpr (MODE == 2) {
-      p0_stage(4, I0);
-      p0_stage(5, I0);
       // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
       f32x4 xr[8][4];
       {
@@ -889,22 +887,17 @@ k_layer(LayerArgs la) {
     // residual fragments: fetched under the last two stages
     // (fp32: 32 x 16 B per lane instead of 48 - the r02i stamps put most of P0's idle time on these two fetches: every CU
     // asks for its residual rows in the same microseconds)
-    // and spread over the last FOUR stages, two tiles (8 loads) in front of each: a quarter of the burst per stage
     f32x4 qr[8][4];
-    auto q_fetch = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) qr[t0 + t][g] = *reinterpret_cast<const f32x4*>(qf + (t0 + t) * 1024 + g * 256);
-    };
-    q_fetch(0);
-    p0_stage(4, I0);
-    q_fetch(2);
-    p0_stage(5, I0);
-    q_fetch(4);
+      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
     p0_stage(6, I0);
-    DDP_LYR_STAMP_AT(13)                                       // residual fetch (three quarters) + stages 4..6
-    q_fetch(6);
+    DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
+#pragma unroll
+    for (int t = 4; t < 8; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
     p0_stage(7, I1);
 
     DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages

@@ -26,9 +26,9 @@ import bench  # noqa: E402
 PHASES = ['P0 rest (second residual fetch + stage 7)', 'P1 residual + LN0 + split', 'fc1 (32 stages)', 'GELU k-block 0 (16x, exposed)',
           'fc2 (32 stages, GELU fillers)', 'LN1 + FiLM + split + q stores', 'P3 value_proj (8 stages + stores)',
           'P3 sampling proj (3 stages + epilogues)', '-', 'tile turnaround / kernel prologue',
-          'P0a tile start (issue first fragments, bias, weight frags)', 'P0b stage 0', 'P0c stages 1-3', 'P0d residual fetch + stages 4-6',
+          'P0a tile start (issue first fragments, bias, weight frags)', 'P0b stage 0', 'P0c stages 1-5', 'P0d residual fetch + stage 6',
           '-', '-']
-MFMAS = [96, 0, 3072, 0, 3072, 0, 768, 288, 0, 0, 0, 96, 288, 288, 0, 0]          # per wave and tile (slot 0 = what is left of P0: stage 7)
+MFMAS = [96, 0, 3072, 0, 3072, 0, 768, 288, 0, 0, 0, 96, 480, 96, 0, 0]          # per wave and tile (slot 0 = what is left of P0: stage 7)
 
 
 def main():
