@@ -73,4 +73,21 @@ for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),
     f = glob.glob(os.path.join(src, pat), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, name))
+for wl in ('city_swin_l_k10_4x1024x2048', 'kitti_depth_k20_16x352x1216', 'bev_fusion_k3_8x200x200'):
+    f = glob.glob(os.path.join(src, 'prof_' + wl, '**', '*kernel_stats.csv'), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(dst, f'{tag}_{wl}_kernel_stats.csv'))
+    d = pmc('pmc_mfma_' + wl)
+    if d:
+        out2 = {}
+        for k, e in d.items():
+            r = {c: round(v[0]) for c, v in e.items()}
+            if r.get('GRBM_GUI_ACTIVE'):
+                r['mfma_busy_frac'] = round(r.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / (r['GRBM_GUI_ACTIVE'] / 8.0), 4)
+            out2[k] = r
+        json.dump(out2, open(os.path.join(dst, f'{tag}_{wl}_pmc_mfma.json'), 'w'), indent=1)
+for name in ('force_dist_rccl_world1.json', 'force_dist_rccl_world1.err'):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f'{tag}_{name}'))
 print('wrote profiles/%s_*' % tag)

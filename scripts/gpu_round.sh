@@ -23,7 +23,18 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/p
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_rd -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_rd.log 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_wr -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_wr.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma -o ddp -- $BENCH > $REPO/$OUT/pmc_mfma.log 2>&1
+# the other BASELINE configurations (per-GPU shards): kernel stats + MFMA-busy counters each
+for wl in city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200; do
+  B2="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --workload $wl"
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_$wl -o ddp -- $B2 > $REPO/$OUT/prof_$wl.log 2>&1
+  timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma_$wl -o ddp -- $B2 > $REPO/$OUT/pmc_mfma_$wl.log 2>&1
+done
 cd $REPO
+# the process-group path of bench.py (RCCL init, 34 MB weight broadcast, replica check by all_gather, barrier, MAX all_reduce)
+# under the launcher at world size 1 - the multi-GPU code path with the one device this box has
+timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
+    --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --force-dist > $OUT/force_dist_rccl_world1.json 2> $OUT/force_dist_rccl_world1.err
+tail -1 $OUT/force_dist_rccl_world1.json | cut -c1-300
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -30 "$f"
 python scripts/collect_profiles.py $TAG --print-only
