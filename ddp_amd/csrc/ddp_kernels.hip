@@ -348,9 +348,10 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
 constexpr int GL_THREADS = 512;
 // tile GL_TH x GL_TW tokens (128 per block: 8 waves x 2 runs of 8 x-adjacent tokens), halo GL_HALO:
 //   window width  GL_WW = TW + 2 HALO + 1: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1 corner
-template <int TH, int TW, int HALO>
+template <int TH, int TW, int HALO, int NT = GL_THREADS>
 struct GlGeom {
-  static_assert(TH * TW == 128 && TW % 8 == 0, "128 tokens per tile, rows of whole 8-token runs");
+  static constexpr int TOK = TH * TW, NW = NT / 64, NG = TOK / (8 * NW);   // NG runs of 8 x-adjacent tokens per wave
+  static_assert(TW % 8 == 0 && NG * 8 * NW == TOK && TOK % (NT / 4) == 0, "rows of whole 8-token runs, whole runs per wave");
   static constexpr int WW = TW + 2 * HALO + 1, WH = TH + 2 * HALO + 1;
   static constexpr int PIX = WW * WH;               // window pixels x 128 B
   static constexpr int DMA = (PIX + 7) / 8;         // LDS-DMA instructions of 8 pixels (1 KiB)
@@ -376,14 +377,21 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // own four values).  Measured shapes (r02c/r02d, C2, ms per launch): 8x16 halo 3 at two blocks per CU 0.206; the same at
 // three blocks per CU (80 registers: spills) 0.232; halo 4 0.215; halo 2 (more fallbacks) 0.251; 4x32 tiles 0.224; a
 // double-buffered 16x16 tile with one 1024-thread block per CU 0.231; the wave-per-token kernels before it 0.278 - 0.314.
-template <int GL_TH, int GL_TW, int GL_HALO, int MINW>
-__global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
+// r02m-r02o (same-box A/B, shipped shape 0.211): 256-token tiles 16x16 / 8x32 (NG = 4, two blocks per CU) 0.216 / 0.217;
+// 8x8 tiles with 256 threads (five blocks per CU) 0.220; one dword per 128-B line of the NEXT head's window requested under
+// this head's taps (L2 prefetch, asynchronous through an LDS-DMA sink) 0.240 - the extra requests cost more than they hide.
+// Counters (profiles/r02o_gather_counters.txt): 65 % of the kernel's L2 requests miss (window lines are re-fetched by the
+// neighbouring tiles: 4 MB of L2 per XCD turn over every ~5 us at this rate), FETCH x 2 + WRITE = 1.37 GB per launch
+// = 6.5 TB/s through the fabric: the kernel is bound by HBM-side traffic at 1.78 x its algorithmic bytes (0.77 GB), not by
+// LDS (IDX_ACTIVE 34 % of a CU's cycles, a quarter of those bank conflicts) or VALU (8 %).
+template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
+__global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
                                                                     int tiles_x, int tiles_y, int n_tiles) {
-  using G = GlGeom<GL_TH, GL_TW, GL_HALO>;
-  constexpr int GL_WW = G::WW, GL_WH = G::WH, GL_PIX = G::PIX, GL_DMA = G::DMA, GL_WIN_B = G::WIN_B;
+  using G = GlGeom<GL_TH, GL_TW, GL_HALO, NT>;
+  constexpr int GL_WW = G::WW, GL_WH = G::WH, GL_PIX = G::PIX, GL_DMA = G::DMA, GL_WIN_B = G::WIN_B, NG = G::NG;
   __shared__ __attribute__((aligned(16))) unsigned char win[GL_WIN_B];
-  __shared__ float msum[8][16];
+  __shared__ float msum[G::NW][16];
   __shared__ int org[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -405,18 +413,22 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
 
   // ---- mean sampling offset per head over the tile's valid tokens (thread = token x head pair)
   {
-    const int tl = tid >> 2, hp = tid & 3;
-    const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
+    const int hp = tid & 3;
     float sx0 = 0.f, sy0 = 0.f, sx1 = 0.f, sy1 = 0.f;
-    if (gy < h && gx < w) {
-      const float* sp = simg + size_t(gy * w + gx) * DDP_SAMP_STRIDE + hp * 16;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(sp + 8), d = *reinterpret_cast<const f32x4*>(sp + 12);
-      const float fx = 4.0f * float(gx), fy = 4.0f * float(gy);
-      sx0 = ((a[0] + a[2]) + (b[0] + b[2])) - fx;
-      sy0 = ((a[1] + a[3]) + (b[1] + b[3])) - fy;
-      sx1 = ((c[0] + c[2]) + (d[0] + d[2])) - fx;
-      sy1 = ((c[1] + c[3]) + (d[1] + d[3])) - fy;
+#pragma unroll
+    for (int ps = 0; ps < G::TOK / (NT / 4); ++ps) {
+      const int tl = ps * (NT / 4) + (tid >> 2);
+      const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
+      if (gy < h && gx < w) {
+        const float* sp = simg + size_t(gy * w + gx) * DDP_SAMP_STRIDE + hp * 16;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(sp + 8), d = *reinterpret_cast<const f32x4*>(sp + 12);
+        const float fx = 4.0f * float(gx), fy = 4.0f * float(gy);
+        sx0 += ((a[0] + a[2]) + (b[0] + b[2])) - fx;
+        sy0 += ((a[1] + a[3]) + (b[1] + b[3])) - fy;
+        sx1 += ((c[0] + c[2]) + (d[0] + d[2])) - fx;
+        sy1 += ((c[1] + c[3]) + (d[1] + d[3])) - fy;
+      }
     }
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) {
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
   if (tid < 16) {
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += msum[k][tid];
+    for (int k = 0; k < G::NW; ++k) v += msum[k][tid];
     const int nv = min(GL_TW, w - x0) * min(GL_TH, h - y0) * 4;
     v = v / float(nv);
     v = fminf(fmaxf(v, -32768.0f), 32768.0f);              // NaN / inf coordinates: any finite origin is fine (fallback path)
@@ -447,12 +459,12 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
 
   const int tk = lane >> 3, q = lane & 7;
   const float xmax = float(w), ymax = float(h);
-  // this lane's two tokens (groups g = 0, 1: two 8-token runs of the wave's tile row)
-  int mtok[2];
-  bool tval[2];
+  // this lane's NG tokens (groups g: runs of 8 x-adjacent tokens of the wave's share of the tile)
+  int mtok[NG];
+  bool tval[NG];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int tl = wave * 16 + g * 8 + tk;
+  for (int g = 0; g < NG; ++g) {
+    const int tl = wave * (NG * 8) + g * 8 + tk;
     const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
     tval[g] = gy < h && gx < w;
     mtok[g] = tval[g] ? gy * w + gx : 0;
@@ -463,16 +475,16 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
     const int ox = __builtin_amdgcn_readfirstlane(org[2 * hd]), oy = __builtin_amdgcn_readfirstlane(org[2 * hd + 1]);
     {
     // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
-    float px_[2], py_[2], pw_[2];
+    float px_[NG], py_[NG], pw_[NG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
       const float* sp = simg + size_t(mtok[g]) * DDP_SAMP_STRIDE + hd * 8;
       px_[g] = sp[2 * (q & 3)];
       py_[g] = sp[2 * (q & 3) + 1];
       pw_[g] = sp[64 - hd * 4 + (q & 3)];                    // (sp already carries + hd * 8)
     }
     // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
-    for (int k = wave; k < GL_DMA; k += GL_THREADS / 64) {
+    for (int k = wave; k < GL_DMA; k += G::NW) {
       int idx = k * 8 + tk;
       idx = idx < GL_PIX ? idx : GL_PIX - 1;
       const int py = idx / GL_WW, px = idx - py * GL_WW;
@@ -484,7 +496,7 @@ __global__ void __launch_bounds__(GL_THREADS, MINW) k_msda_gather_lds(const floa
     __syncthreads();
     // ---- taps
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
       // tokens outside the map (ragged tile) sample the window centre with a result that is never stored
       const float xv = tval[g] ? px_[g] : float(ox + GL_HALO), yv = tval[g] ? py_[g] : float(oy + GL_HALO);
       const float x = __builtin_amdgcn_fmed3f(xv, -1.0f, xmax), y = __builtin_amdgcn_fmed3f(yv, -1.0f, ymax);
@@ -1401,11 +1413,11 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                               hipStream_t st) {
-  constexpr int TH = 8, TW = 16;
+  constexpr int TH = 8, TW = 16, NT = GL_THREADS;
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
-  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4>), dim3(cdiv(n_tiles, 8) * 8), dim3(GL_THREADS), 0, st, vpad, samp, out_sb, n_tok,
+  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(cdiv(n_tiles, 8) * 8), dim3(NT), 0, st, vpad, samp, out_sb, n_tok,
                      h, w, tiles_x, tiles_y, n_tiles);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");

@@ -8,8 +8,9 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "from ddp_amd import build; print(build.source_hash())" > $OUT/source_sha.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.txt
-cat $OUT/pytest_gpu.txt
+# -s: the full-size parity tests and the bf16x3 arithmetic tests print the figures DESIGN.md quotes
+python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids\|^$" > $OUT/pytest_gpu.txt
+tail -3 $OUT/pytest_gpu.txt
 python bench.py --steps 10 --warmup 2 --next-rows > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json; tail -3 $OUT/bench.err
 REPO=$PWD
