@@ -4,6 +4,10 @@
 #include <stddef.h>
 #include "../../include/ddp_mi355x.h"
 
+// The sample table the layer kernel's P3 epilogue hands to the LDS-staged gather is head-major: [head][token][8 pixel
+// coordinates | 4 attention weights] (the gather runs one head per block); the standalone GEMM epilogue / wave-per-token
+// gathers keep token-major rows of DDP_SAMP_STRIDE floats.  Same size, same workspace slot.
+
 namespace ddp {
 
 void set_error(const char* fmt, ...);

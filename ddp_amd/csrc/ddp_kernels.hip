@@ -327,10 +327,11 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
 // ------------------------------------------------------------------------------------------------
 // LDS-staged gather ("deformable-offset gathers staged through LDS", north_star).  The tap traffic of the wave-per-
 // token kernels above is 16 KiB of L2 -> L1 requests per token for 1 KiB of unique value data; here a block owns a
-// GL_TH x GL_TW tile of tokens of one map and, head by head, stages that head's 128-B slice of the value map for the
+// GL_TH x GL_TW tile of tokens of one map and ONE head: it stages that head's 128-B slice of the value map for the
 // tile plus a halo into LDS by LDS-DMA (one 1-KiB instruction = 8 pixels x 128 B, coalesced), then serves the 16 bilinear
 // taps of every token from LDS (ds_read_b128, the four corners as immediate offsets of one address).  Fill traffic is
-// (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.7 x 1 KiB per token instead of 16 KiB.
+// (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.7 x 128 B per (token, head) instead of 2 KiB, and - heads pinned to XCDs, see the
+// kernel - the 1.7 x that is halo comes out of L2, not HBM.
 //   * The window of head hd is centred on the tile's MEAN sampling offset of that head (a block reduction over the
 //     tile's 4 x 128 sample points, deterministic): the reference initialises the offsets as a ring of radius 1..4 px per
 //     head (multi_scale_deform_attn.py:233-244), so the points of a head spread +-1.5 px around their mean and
@@ -387,20 +388,22 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
 __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
-                                                                    int tiles_x, int tiles_y, int n_tiles) {
+                                                                    int tiles_x, int tiles_y, int n_tiles, int m_total) {
   using G = GlGeom<GL_TH, GL_TW, GL_HALO, NT>;
   constexpr int GL_WW = G::WW, GL_WH = G::WH, GL_PIX = G::PIX, GL_DMA = G::DMA, GL_WIN_B = G::WIN_B, NG = G::NG;
   __shared__ __attribute__((aligned(16))) unsigned char win[GL_WIN_B];
-  __shared__ float msum[G::NW][16];
-  __shared__ int org[16];
+  __shared__ float msum[G::NW][2];
+  __shared__ int org[2];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware block -> tile map: consecutive block ids land on different XCDs (8 L2s); each XCD walks a contiguous run
-  // of tiles so that neighbouring tiles (shared halos) meet in the same L2
-  const int per = (n_tiles + 7) >> 3;
-  const int tile = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-  if (tile >= n_tiles || (int(blockIdx.x) >> 3) >= per) return;
+  // ONE head per block, head = block id mod 8 = the XCD the block lands on (workgroups go round-robin over the 8 XCDs): an
+  // XCD's L2 only ever holds its head's 128-B slices, and its ~96 resident blocks work on neighbouring tiles of the same head
+  // at the same time, so the halo lines neighbouring tiles share are L2 hits instead of HBM re-reads (r02p: FETCH_SIZE x 2
+  // 972 -> 375 MB per launch = the algorithmic 268 MB map + 100 MB table; 0.210 -> 0.197 ms at C2, 0.445 -> 0.374 at C3)
+  const int tile = int(blockIdx.x) >> 3;
+  if (tile >= n_tiles) return;
+  const int hd = int(blockIdx.x) & 7;
   const int tpi = tiles_x * tiles_y;
   const int img = tile / tpi;
   const int t2 = tile - img * tpi;
@@ -408,51 +411,40 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
   const int y0 = tyi * GL_TH, x0 = (t2 - tyi * tiles_x) * GL_TW;
   const int wp = w + 2;
   const float* vimg = vpad + size_t(img) * size_t(h + 2) * wp * 256;
-  const float* simg = samp + size_t(img) * n_tok * DDP_SAMP_STRIDE;
+  // head-major sample table [head][token][8 pixel coordinates | 4 attention weights] (written by the layer kernel's P3)
+  const float* simg = samp + (size_t(hd) * m_total + size_t(img) * n_tok) * 12;
   const unsigned lds_win = (unsigned)(size_t)(lds_byte_t*)win;
 
-  // ---- mean sampling offset per head over the tile's valid tokens (thread = token x head pair)
+  // ---- mean sampling offset of the head over the tile's valid tokens (thread = token x sample point)
   {
-    const int hp = tid & 3;
-    float sx0 = 0.f, sy0 = 0.f, sx1 = 0.f, sy1 = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < G::TOK / (NT / 4); ++ps) {
-      const int tl = ps * (NT / 4) + (tid >> 2);
-      const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
-      if (gy < h && gx < w) {
-        const float* sp = simg + size_t(gy * w + gx) * DDP_SAMP_STRIDE + hp * 16;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(sp + 8), d = *reinterpret_cast<const f32x4*>(sp + 12);
-        const float fx = 4.0f * float(gx), fy = 4.0f * float(gy);
-        sx0 += ((a[0] + a[2]) + (b[0] + b[2])) - fx;
-        sy0 += ((a[1] + a[3]) + (b[1] + b[3])) - fy;
-        sx1 += ((c[0] + c[2]) + (d[0] + d[2])) - fx;
-        sy1 += ((c[1] + c[3]) + (d[1] + d[3])) - fy;
-      }
+    static_assert(G::TOK * 4 == NT, "one (token, point) per thread");
+    const int tl = tid >> 2, p = tid & 3;
+    const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
+    float sx = 0.f, sy = 0.f;
+    if (gy < h && gx < w) {
+      const float* sp = simg + size_t(gy * w + gx) * 12 + 2 * p;
+      sx = sp[0] - float(gx);
+      sy = sp[1] - float(gy);
     }
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1) {
-      sx0 += __shfl_xor(sx0, o, 64);
-      sy0 += __shfl_xor(sy0, o, 64);
-      sx1 += __shfl_xor(sx1, o, 64);
-      sy1 += __shfl_xor(sy1, o, 64);
+    for (int o = 1; o < 64; o <<= 1) {
+      sx += __shfl_xor(sx, o, 64);
+      sy += __shfl_xor(sy, o, 64);
     }
-    if (lane < 4) {
-      msum[wave][lane * 4 + 0] = sx0;
-      msum[wave][lane * 4 + 1] = sy0;
-      msum[wave][lane * 4 + 2] = sx1;
-      msum[wave][lane * 4 + 3] = sy1;
+    if (lane == 0) {
+      msum[wave][0] = sx;
+      msum[wave][1] = sy;
     }
   }
   __syncthreads();
-  if (tid < 16) {
+  if (tid < 2) {
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < G::NW; ++k) v += msum[k][tid];
     const int nv = min(GL_TW, w - x0) * min(GL_TH, h - y0) * 4;
     v = v / float(nv);
     v = fminf(fmaxf(v, -32768.0f), 32768.0f);              // NaN / inf coordinates: any finite origin is fine (fallback path)
-    // tid = hd*2 + axis: window origin in map coordinates
+    // tid = axis: window origin in map coordinates
     org[tid] = ((tid & 1) ? y0 : x0) + int(rintf(v)) - GL_HALO;
   }
   __syncthreads();
@@ -471,17 +463,17 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
   }
   const size_t img_tok = size_t(img) * n_tok;
 
-  for (int hd = 0; hd < 8; ++hd) {
-    const int ox = __builtin_amdgcn_readfirstlane(org[2 * hd]), oy = __builtin_amdgcn_readfirstlane(org[2 * hd + 1]);
+  {
+    const int ox = __builtin_amdgcn_readfirstlane(org[0]), oy = __builtin_amdgcn_readfirstlane(org[1]);
     {
     // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
     float px_[NG], py_[NG], pw_[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const float* sp = simg + size_t(mtok[g]) * DDP_SAMP_STRIDE + hd * 8;
+      const float* sp = simg + size_t(mtok[g]) * 12;
       px_[g] = sp[2 * (q & 3)];
       py_[g] = sp[2 * (q & 3) + 1];
-      pw_[g] = sp[64 - hd * 4 + (q & 3)];                    // (sp already carries + hd * 8)
+      pw_[g] = sp[8 + (q & 3)];
     }
     // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
     for (int k = wave; k < GL_DMA; k += G::NW) {
@@ -593,7 +585,6 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
       }
     }
     }
-    __syncthreads();                                       // every wave is done reading before the next head's fill
   }
 }
 
@@ -1417,8 +1408,8 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
-  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(cdiv(n_tiles, 8) * 8), dim3(NT), 0, st, vpad, samp, out_sb, n_tok,
-                     h, w, tiles_x, tiles_y, n_tiles);
+  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb, n_tok, h, w,
+                     tiles_x, tiles_y, n_tiles, rows);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");
 }

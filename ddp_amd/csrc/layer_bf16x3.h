@@ -72,7 +72,7 @@ struct LayerArgs {
   int M;
   int has_next;                  // also emit the next layer's value / sampling projections
   float* v_out;                  // fp32 rows of 256, ZERO-PADDED map: token (b,i,j) -> row b*(h+2)*(w+2) + (i+1)*(w+2) + (j+1)
-  float* samp_out;               // (M,96): 64 pixel coordinates + 32 attention weights
+  float* samp_out;               // (8 heads, M, 12): per head and token 4 x (x, y) pixel coordinates + 4 attention weights
   const float* py;               // next layer's positional tables (h,96) / (w,96), bias folded in
   const float* px;
   int n_tok, w;
@@ -1175,7 +1175,6 @@ k_layer(LayerArgs la) {
             if (sc2 == 1 && t == 1) continue;                 // one 32-column tile only
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int col = sc2 * 64 + t * 32 + 8 * g + 4 * h;
               f32x4 v = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]} + pos[t][g];
               if (sc2 == 0) {                                  // sampling offsets -> pixel coordinates (x, y, x, y)
                 v[0] += fj; v[1] += fi; v[2] += fj; v[3] += fi;
@@ -1189,7 +1188,10 @@ k_layer(LayerArgs la) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= inv;
               }
-              *reinterpret_cast<f32x4*>(la.samp_out + size_t(m) * 96 + col) = v;
+              // head-major table [head][token][8 coordinates | 4 weights]: the gather runs one head per block.  This lane's four
+              // columns are sc2 * 64 + t * 32 + 8g + 4h ..: coordinates of head 4t + g (points 2h, 2h + 1) / weights of head 2g + h
+              const int shd = sc2 == 0 ? (t * 4 + g) : 2 * g + h;
+              *reinterpret_cast<f32x4*>(la.samp_out + (size_t(shd) * M + m) * 12 + (sc2 == 0 ? 4 * h : 8)) = v;
             }
           }
         }
