@@ -9,7 +9,7 @@
 //
 // Why one kernel.  With the 2.65x faster bf16x3 contractions the layer was HBM bound; every tensor between these
 // GEMMs (q1, the 1024-wide hidden activation, and q' as the operand of the next projections) now stays in the
-// register file.  Per token the kernel reads s (1.5 KiB) + q (1.5 KiB) and writes q' (1.5 KiB) + v' (1 KiB) +
+// register file.  Per token the kernel reads s (1.5 KiB, SB) + q (1 KiB, fp32) and writes q' (1 KiB) + v' (1 KiB) +
 // samp' (0.4 KiB).
 //
 //   * a wave owns 32 tokens; the block's 4 waves (one per SIMD, 512 registers each) share the weight stream;
@@ -32,8 +32,14 @@
 //   * behind one MFMA a single wave hides 5 independent instructions but only 3 of one dependency chain
 //     (scripts/ubench/mfma_fill.hip): every MFMA has its own filler slot, and GELU + split of k-block n+1 is handed
 //     out to the slots of k-block n as single instructions of four values at a time (GELU_SCHED).
-// The same machinery in MODE 1 is the tail of a segmentation step (conv_seg, argmax, softmax accumulation, x0 LUT,
-// DDIM update of the noisy map kept as SB).
+// The same machinery runs the other per-step pieces (template parameter MODE):
+//   1  tail of a segmentation step: conv_seg, argmax, softmax accumulation (+ the legacy update of an SB noisy map);
+//   2  head of the FIRST step: q = W_m . noise + (W_x x + b), u_0 = W_m . noise kept in fp32, layer 0's projections;
+//   3  layer 0's projections alone (bev, ddp_head_forward) / the depth step head (one-channel concat-conv, no GEMM);
+//   4  tail of step s fused with the head of step s + 1: the DDIM update runs on u = W_m . m (affine in u and a row of
+//      the table W_m . LUT) - no concat-conv GEMM and no 256-channel noisy map after step 0.
+// Where the cycles of MODE 0 go is measured, not estimated: -DDDP_LYR_STAMP builds + scripts/stamp_layer.py
+// (profiles/r02_layer_cycle_stamps*.json).
 #pragma once
 #include <type_traits>
 
