@@ -501,53 +501,71 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
       const float wa = pw_[g] * (1.f - fy), wb = pw_[g] * fy;
       const float w00 = wa * (1.f - fx), w01 = wa * fx, w10 = wb * (1.f - fx), w11 = wb * fx;
       const bool staged = __builtin_amdgcn_ballot_w64(!inwin) == 0;       // wave-uniform: every corner of the 8 tokens is in LDS
-      // staged: byte offset of the point's top-left corner in the window; else in the padded map of this image
-      const int aoff = staged ? (ry * GL_WW + rx) * 128 : int(unsigned((iy + 1) * wp + ix + 1) * 1024u + unsigned(hd * 128));
+      // byte offset of the point's top-left corner: in the window when all four corners are staged, else in the padded map of
+      // this image
+      const int aoff = inwin ? (ry * GL_WW + rx) * 128 : int(unsigned((iy + 1) * wp + ix + 1) * 1024u + unsigned(hd * 128));
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      auto point = [&](auto ppc, auto stagedc) __attribute__((always_inline)) {
-        // fetch point pp from lane (token, pp) of this token's 8 lanes: lane' = (lane & 0x18) | pp within each 32-lane half
-        // (ds_swizzle bit mode: and_mask [4:0], or_mask [9:5], xor_mask [14:10])
-        constexpr int pat = (decltype(ppc)::value << 5) | 0x18;
-        const int o = __builtin_amdgcn_ds_swizzle(aoff, pat);
-        const float a00 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w00), pat));
-        const float a01 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w01), pat));
-        const float a10 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w10), pat));
-        const float a11 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w11), pat));
-        f32x4 v00, v01, v10, v11;
-        if constexpr (decltype(stagedc)::value) {
-          // explicit LDS address space: a generic pointer would let the two paths be merged into flat loads
-          const lds_byte_t* a = (const lds_byte_t*)win + (o + q * 16);
-          v00 = *reinterpret_cast<const lds_f32x4_t*>(a);
-          v01 = *reinterpret_cast<const lds_f32x4_t*>(a + 128);
-          v10 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128);
-          v11 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128 + 128);
-        } else {
-          const char* vb = reinterpret_cast<const char*>(vimg) + q * 16;
-          const unsigned o00 = unsigned(o);
-          v00 = *reinterpret_cast<const f32x4*>(vb + o00);
-          v01 = *reinterpret_cast<const f32x4*>(vb + o00 + 1024u);
-          v10 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u);
-          v11 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u + 1024u);
-        }
-        // one explicit fma chain per channel: the same arithmetic on both paths
+      // one sample point for the token's 8 lanes: four corner loads of 16 B, one explicit fma chain per channel (the same
+      // arithmetic whichever memory the corners come from)
+      auto corners_lds = [&](int o, f32x4& v00, f32x4& v01, f32x4& v10, f32x4& v11) __attribute__((always_inline)) {
+        // explicit LDS address space: a generic pointer would let the two paths be merged into flat loads
+        const lds_byte_t* a = (const lds_byte_t*)win + (o + q * 16);
+        v00 = *reinterpret_cast<const lds_f32x4_t*>(a);
+        v01 = *reinterpret_cast<const lds_f32x4_t*>(a + 128);
+        v10 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128);
+        v11 = *reinterpret_cast<const lds_f32x4_t*>(a + GL_WW * 128 + 128);
+      };
+      auto accumulate = [&](const f32x4& v00, const f32x4& v01, const f32x4& v10, const f32x4& v11, float a00, float a01, float a10,
+                            float a11) __attribute__((always_inline)) {
         acc = __builtin_elementwise_fma(v00, f32x4{a00, a00, a00, a00}, acc);
         acc = __builtin_elementwise_fma(v01, f32x4{a01, a01, a01, a01}, acc);
         acc = __builtin_elementwise_fma(v10, f32x4{a10, a10, a10, a10}, acc);
         acc = __builtin_elementwise_fma(v11, f32x4{a11, a11, a11, a11}, acc);
       };
       if (staged) {
-        point(std::integral_constant<int, 0>{}, std::true_type{});
-        point(std::integral_constant<int, 1>{}, std::true_type{});
-        point(std::integral_constant<int, 2>{}, std::true_type{});
-        point(std::integral_constant<int, 3>{}, std::true_type{});
-      } else {                                                   // rare: one point at a time (4 loads in flight)
-        point(std::integral_constant<int, 0>{}, std::false_type{});
-        __builtin_amdgcn_sched_barrier(0);
-        point(std::integral_constant<int, 1>{}, std::false_type{});
-        __builtin_amdgcn_sched_barrier(0);
-        point(std::integral_constant<int, 2>{}, std::false_type{});
-        __builtin_amdgcn_sched_barrier(0);
-        point(std::integral_constant<int, 3>{}, std::false_type{});
+        auto point = [&](auto ppc) __attribute__((always_inline)) {
+          // fetch point pp from lane (token, pp) of this token's 8 lanes: lane' = (lane & 0x18) | pp within each 32-lane half
+          // (ds_swizzle bit mode: and_mask [4:0], or_mask [9:5], xor_mask [14:10])
+          constexpr int pat = (decltype(ppc)::value << 5) | 0x18;
+          const int o = __builtin_amdgcn_ds_swizzle(aoff, pat);
+          const float a00 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w00), pat));
+          const float a01 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w01), pat));
+          const float a10 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w10), pat));
+          const float a11 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w11), pat));
+          f32x4 v00, v01, v10, v11;
+          corners_lds(o, v00, v01, v10, v11);
+          accumulate(v00, v01, v10, v11, a00, a01, a10, a11);
+        };
+        point(std::integral_constant<int, 0>{});
+        point(std::integral_constant<int, 1>{});
+        point(std::integral_constant<int, 2>{});
+        point(std::integral_constant<int, 3>{});
+      } else {
+        // some corner of the group is outside the window.  One point at a time (rolled: the registers of one point); the
+        // (token, point) pairs whose corners ARE staged still read LDS, only the others go to global memory - lane-divergent,
+        // both sides run, but the L2 -> L1 tap traffic that makes the global path slow shrinks with the staged fraction
+#pragma unroll 1
+        for (int pp = 0; pp < 4; ++pp) {
+          const int src = ((lane & 0x38) | pp) << 2;           // lane (token, pp) of this token's 8 lanes
+          const int o = __builtin_amdgcn_ds_bpermute(src, aoff);
+          const bool from_lds = __builtin_amdgcn_ds_bpermute(src, int(inwin)) != 0;
+          const float a00 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w00)));
+          const float a01 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w01)));
+          const float a10 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w10)));
+          const float a11 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w11)));
+          f32x4 v00, v01, v10, v11;
+          if (from_lds) {
+            corners_lds(o, v00, v01, v10, v11);
+          } else {
+            const char* vb = reinterpret_cast<const char*>(vimg) + q * 16;
+            const unsigned o00 = unsigned(o);
+            v00 = *reinterpret_cast<const f32x4*>(vb + o00);
+            v01 = *reinterpret_cast<const f32x4*>(vb + o00 + 1024u);
+            v10 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u);
+            v11 = *reinterpret_cast<const f32x4*>(vb + o00 + unsigned(wp) * 1024u + 1024u);
+          }
+          accumulate(v00, v01, v10, v11, a00, a01, a10, a11);
+        }
       }
       // exact 3-way split of this lane's four channels, THEN the quad exchange with lane q ^ 2 (the other half of the
       // 16-B slot): 6 packed dwords travel instead of 4 fp32 + a second split

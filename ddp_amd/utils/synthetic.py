@@ -54,12 +54,24 @@ def _offset_ring_bias():
     return grid.reshape(-1)
 
 
-def encoder_layer_state(gen, prefix, sd):
+# Weight profiles.  'init': the reference's initialisation plus small perturbations (offsets = the per-head ring +- 0.3 px,
+# 0.3 px of content-dependent spread: what every number in DESIGN.md is quoted on).  'trained_like': what training does to
+# these parameters, exaggerated - content-dependent offsets of +- 2.4 px on top of a ring perturbed by 1 px (taps far from
+# the tile's mean offset: the gather's global-memory path, windows clamped at the map border), peaked attention weights
+# and 8x larger class scores (few near-ties).  No checkpoint exists in this image; this profile is a stress test, not data.
+PROFILES = {
+    'init': dict(off_w=0.02, off_b=0.3, attn_w=0.05, attn_b=1.0, seg_gain=1.0),
+    'trained_like': dict(off_w=0.15, off_b=1.0, attn_w=0.3, attn_b=2.0, seg_gain=8.0),
+}
+
+
+def encoder_layer_state(gen, prefix, sd, profile='init'):
+    pr = PROFILES[profile]
     a = prefix + 'attentions.0.'
-    sd[a + 'sampling_offsets.weight'] = _normal(gen, (HEADS * POINTS * 2, EMBED), std=0.02)
-    sd[a + 'sampling_offsets.bias'] = _offset_ring_bias() + _normal(gen, (HEADS * POINTS * 2,), std=0.3)
-    sd[a + 'attention_weights.weight'] = _normal(gen, (HEADS * POINTS, EMBED), std=0.05)
-    sd[a + 'attention_weights.bias'] = _normal(gen, (HEADS * POINTS,), std=1.0)
+    sd[a + 'sampling_offsets.weight'] = _normal(gen, (HEADS * POINTS * 2, EMBED), std=pr['off_w'])
+    sd[a + 'sampling_offsets.bias'] = _offset_ring_bias() + _normal(gen, (HEADS * POINTS * 2,), std=pr['off_b'])
+    sd[a + 'attention_weights.weight'] = _normal(gen, (HEADS * POINTS, EMBED), std=pr['attn_w'])
+    sd[a + 'attention_weights.bias'] = _normal(gen, (HEADS * POINTS,), std=pr['attn_b'])
     sd[a + 'value_proj.weight'] = _xavier(gen, EMBED, EMBED)
     sd[a + 'value_proj.bias'] = _normal(gen, (EMBED,), std=0.02)
     sd[a + 'output_proj.weight'] = _xavier(gen, EMBED, EMBED)
@@ -83,7 +95,7 @@ def time_mlp_state(gen, sd):
     sd['time_mlp.3.bias'] = _uniform(gen, (TIME_DIM,), 1.0 / math.sqrt(TIME_DIM))
 
 
-def make_state_dict(task='seg', num_classes=150, num_layers=6, feat_channels=256, seed=2):
+def make_state_dict(task='seg', num_classes=150, num_layers=6, feat_channels=256, seed=2, profile='init'):
     """Hot-path ``state_dict`` (CPU fp32) for ``task`` in {'seg', 'depth', 'bev'}.
 
     seg  : segmentation/mmseg/models/segmentors/ddp.py:78,92-112 + decode head
@@ -106,12 +118,12 @@ def make_state_dict(task='seg', num_classes=150, num_layers=6, feat_channels=256
     if task != 'depth':
         sd['embedding_table.weight'] = _normal(gen, (num_classes + 1, EMBED))
     for l in range(num_layers):
-        encoder_layer_state(gen, f'decode_head.encoder.layers.{l}.', sd)
+        encoder_layer_state(gen, f'decode_head.encoder.layers.{l}.', sd, profile)
     if task == 'depth':
         sd['decode_head.conv_depth.weight'] = _xavier(gen, 1, EMBED, 3, 3) * 4.0
         sd['decode_head.conv_depth.bias'] = _normal(gen, (1,), mean=2.0, std=0.1)
     else:
-        sd['decode_head.conv_seg.weight'] = _xavier(gen, num_classes, EMBED, 1, 1)
+        sd['decode_head.conv_seg.weight'] = _xavier(gen, num_classes, EMBED, 1, 1) * PROFILES[profile]['seg_gain']
         sd['decode_head.conv_seg.bias'] = _normal(gen, (num_classes,), std=0.02)
     return sd
 

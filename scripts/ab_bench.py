@@ -33,12 +33,13 @@ def main():
     ap.add_argument('--workload', default='ade_swin_t_k3_8x512x1024')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--profile', default='init', help="weight profile (ddp_amd/utils/synthetic.py PROFILES): 'trained_like' spreads the sampling offsets")
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     wl = bench.WORKLOADS[args.workload]
     task, cx = wl['task'], wl.get('feat_channels', 256)
     cm = 1 if task == 'depth' else 256
-    sd = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2)
+    sd = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2, profile=args.profile)
     weights = PackedWeights(sd, task, wl['num_layers'], dev)
     x, noise = synthetic.make_inputs(wl['batch'], wl['h'], wl['w'], wl['randsteps'], cx, cm, seed=0)
     dx, dn = x.to(dev), noise.to(dev)
