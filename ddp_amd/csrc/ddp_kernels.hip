@@ -385,6 +385,8 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // neighbouring tiles: 4 MB of L2 per XCD turn over every ~5 us at this rate), FETCH x 2 + WRITE = 1.37 GB per launch
 // = 6.5 TB/s through the fabric: the kernel is bound by HBM-side traffic at 1.78 x its algorithmic bytes (0.77 GB), not by
 // LDS (IDX_ACTIVE 34 % of a CU's cycles, a quarter of those bank conflicts) or VALU (8 %).
+// r02p: one head per block, head = XCD (below): 0.210 -> 0.197.  r02t, in that form: 8x8 tiles / 256 threads 0.197, 4x16 tiles /
+// 256 threads 0.199 against 0.183 - 0.195 for 8x16 on the same box.
 template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
 __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
