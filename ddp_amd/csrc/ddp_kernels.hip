@@ -386,7 +386,9 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // = 6.5 TB/s through the fabric: the kernel is bound by HBM-side traffic at 1.78 x its algorithmic bytes (0.77 GB), not by
 // LDS (IDX_ACTIVE 34 % of a CU's cycles, a quarter of those bank conflicts) or VALU (8 %).
 // r02p: one head per block, head = XCD (below): 0.210 -> 0.197.  r02t, in that form: 8x8 tiles / 256 threads 0.197, 4x16 tiles /
-// 256 threads 0.199 against 0.183 - 0.195 for 8x16 on the same box.
+// 256 threads 0.199 against 0.183 - 0.195 for 8x16 on the same box.  r02u: persistent blocks (3 or 6 per CU and head, tile loop,
+// the next tile's table entries fetched under the current tile's taps) 0.213 - 0.217 against 0.197: one short block per
+// (tile, head), scheduled by the hardware as LDS frees up, overlaps better than a block-level software pipeline.
 template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
 __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
