@@ -33,3 +33,24 @@ def test_layer_kernels_have_no_scratch(tmp_path):
         assert vgpr <= 512
     for name, (scratch, vgpr) in gemm.items():
         assert vgpr <= 256, f'{name}: {vgpr} registers (two 512-thread blocks per CU need <= 256)'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+def test_gather_fits_three_blocks_per_cu(tmp_path):
+    """the LDS-staged gather overlaps fill and taps ACROSS blocks (three 512-thread blocks per CU = 6 waves per SIMD): no
+    scratch, <= 85 registers, and a window + bookkeeping of at most 160 KiB / 3 of LDS"""
+    out = tmp_path / 'kernels.s'
+    src = os.path.join(ROOT, 'ddp_amd', 'csrc', 'ddp_kernels.hip')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-x', 'hip', src,
+                    '--cuda-device-only', '-S', '-o', str(out)], check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    found = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', text, re.S):
+        if 'k_msda_gather_lds' not in m.group(1):
+            continue
+        found += 1
+        body = m.group(2)
+        assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0
+        assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 85
+        assert int(re.search(r'\.amdhsa_group_segment_fixed_size (\d+)', body).group(1)) <= 160 * 1024 // 3
+    assert found == 1
