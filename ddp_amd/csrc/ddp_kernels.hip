@@ -336,10 +336,10 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
 //     tile's 4 x 128 sample points, deterministic): the reference initialises the offsets as a ring of radius 1..4 px per
 //     head (multi_scale_deform_attn.py:233-244), so the points of a head spread +-1.5 px around their mean and
 //     GL_HALO = 3 leaves 1.5 px for the learned, position- and content-dependent part.
-//   * A point whose four corners are not all inside the window is served from global memory with the padded-map
-//     arithmetic of k_msda_gather_sb_pad (wave-uniform branch per point): any offset is handled, only slower.  Both paths
-//     load the same values and combine them in the same order, so the result does not depend on which one ran.
-//   * wave = 8 x-adjacent tokens x 8 channel quads of ONE head (as k_msda_gather_sb_pad_t8); the 32 channels of
+//   * A (token, point) whose four corners are not all inside the window is served from the zero-padded map in global
+//     memory (an 8-token group with such a point takes a lane-divergent mixed path): any offset is handled, only slower.
+//     Both paths load the same values and combine them in the same order, so the result does not depend on which one ran.
+//   * wave = 8 x-adjacent tokens x 8 channel quads of ONE head; the 32 channels of
 //     (token, head) are K16 blocks 2hd, 2hd+1 of the SB operand: lane pairs (q, q^2) are joined by one DPP quad
 //     permute per register and written straight to HBM as 16-B slots (128-B runs of 8 tokens) - no LDS output tile.
 // Addresses: per-image scalar base + 32-bit offsets (an image's padded map is < 4 GiB).

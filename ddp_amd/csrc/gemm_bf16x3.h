@@ -9,10 +9,11 @@
 // and a bf16 x bf16 product is exact in fp32, so with fp32 accumulation inside the MFMA
 //     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + O(2^-24 |a||b|)
 // Six bf16 MFMAs replace eight fp32 MFMAs of half the K each: 6 x 32 cycles per 32x32x16 block instead of
-// 8 x 64, a 2.67x higher ceiling (417 TFLOP/s fp32-equivalent) at fp32-class accuracy - measured max
-// error 2.3e-7 of max|C| at K = 1024 against 4.9e-7 for a plain fp32 GEMM (the dropped terms a2b3, a3b2,
-// a3b3 are below one fp32 ulp of the product).  This is NOT a reduced-precision mode: parity tests run
-// against the same fp32 oracle with the same tolerances.
+// 8 x 64, a 2.67x higher ceiling (417 TFLOP/s fp32-equivalent) at fp32-class accuracy (the dropped terms a2b3, a3b2,
+// a3b3 are below one fp32 ulp of the product).  The claim is a test (ddp_linear_b3 + tests/test_b3_arithmetic.py, against
+// fp64): worst error 5.7 .. 8.8 units of 2^-24 sum|a||w| at K = 256 .. 1024 where the exact-product fp32 MFMA engine
+// measures 6.4 .. 9.0 on the same operands, wide-dynamic-range, cancelling and near-subnormal rows included.  This is
+// NOT a reduced-precision mode: parity tests run against the same fp32 oracle with the same tolerances.
 //
 // Layouts
 //  * weights are split + K-permuted once per ddp_prepare into Wp[comp][n][K] (bf16, comp = 0..2):
