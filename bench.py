@@ -356,12 +356,13 @@ def main():
         n_img = max(1, min(args.cpu_images if headline else 1, B))
         r = wl['randsteps']
 
-        def oracle_run(b, steps=K, dtype=torch.float32, accumulation=wl['accumulation']):
+        def oracle_run(b, steps=K, dtype=torch.float32, accumulation=wl['accumulation'], x0_index=None):
             """the reference's sampler for ONE image of the batch (the reference loop is b = 1), restated on the CPU"""
             xs, ns = x[b:b + 1].to(dtype), noise[b].to(dtype)
             sdd = sd if dtype == torch.float32 else {k: v.to(dtype) for k, v in sd.items()}
             if task == 'seg':
-                return O.ddim_sample_seg(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'], accumulation=accumulation)
+                return O.ddim_sample_seg(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'], accumulation=accumulation,
+                                         x0_index=x0_index)
             if task == 'depth':
                 return O.sample_depth(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'])
             return O.ddim_sample_bev(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'],
@@ -387,6 +388,20 @@ def main():
         parity = {'max_rel_vs_oracle': worst, 'images_checked': n_img, 'pixels_above_1e-4': bad_px, 'gate': 1e-3}
         if task != 'depth':
             parity['argmax_agreement' if task == 'seg' else 'thresholded_agreement'] = agree
+        # (seg, one noisy map per image) the same comparison with the loop's only discontinuity taken out: the engine records the
+        # class it fed back at every step (DDP_FLAG_RECORD_X0) and the oracle takes THOSE decisions instead of its own
+        # argmax - what is left is arithmetic (tests/test_full_size_parity.py asserts this figure and bounds the decisions)
+        if task == 'seg' and r == 1:
+            try:
+                engd = DDPEngine(sd, task, **dict(kw, batch=1, record_x0=True, weights=weights))
+                gd = engd.sample(dx[:1].contiguous(), dn[:1].contiguous()).cpu()
+                tr = engd.x0_trace()[:, :1].cpu().long()
+                refd = oracle_run(0, x0_index=[tr[s] for s in range(K)])
+                parity['max_rel_decisions_fed'] = float(((gd - refd).abs().amax(1) / refd.abs().max()).max())
+                parity['same_bits_as_batch_call'] = bool(torch.equal(gd, gpu_out[:1]))
+                del engd
+            except Exception as e:
+                parity['max_rel_decisions_fed'] = {'error': str(e)[:200]}
         # The K-step output feeds argmax back into the next step, so ONE near-tie pixel that rounds the other way moves
         # a ~20x20 neighbourhood by 1e-4..1e-3 (SURVEY.md §7 hard part 1) in any fp32 implementation.  The feedback-free
         # figure: single-step scores (K=1, no accumulation) of image 0 against an fp64 evaluation of the oracle, beside

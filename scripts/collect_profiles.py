@@ -77,6 +77,9 @@ for wl in ('city_swin_l_k10_4x1024x2048', 'kitti_depth_k20_16x352x1216', 'bev_fu
     f = glob.glob(os.path.join(src, 'prof_' + wl, '**', '*kernel_stats.csv'), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f'{tag}_{wl}_kernel_stats.csv'))
+    f = os.path.join(src, f'bench_{wl}.json')
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f'{tag}_{wl}_bench.json'))
     d = pmc('pmc_mfma_' + wl)
     if d:
         out2 = {}

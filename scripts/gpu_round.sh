@@ -31,6 +31,11 @@ for wl in city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_
   timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma_$wl -o ddp -- $B2 > $REPO/$OUT/pmc_mfma_$wl.log 2>&1
 done
 cd $REPO
+# the other BASELINE configurations as plain bench lines: throughput, roofline, CPU baseline and full-size parity of one image
+for wl in city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200; do
+  timeout 400 python bench.py --workload $wl --steps 3 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+  tail -1 $OUT/bench_$wl.json | cut -c1-200
+done
 # the process-group path of bench.py (RCCL init, 34 MB weight broadcast, replica check by all_gather, barrier, MAX all_reduce)
 # under the launcher at world size 1 - the multi-GPU code path with the one device this box has
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
