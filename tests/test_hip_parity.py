@@ -402,6 +402,34 @@ def test_sample_more_tiles_than_cus_ragged(dev):
     assert max_rel(out, ref) < REL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w', [(37, 53), (8, 16), (70, 9)])
+def test_sample_spread_offsets_ragged_maps(dev, h, w):
+    """the LDS-staged gather's mixed path (sampling offsets spread far beyond the window: 'trained_like' profile) on maps that are
+    not multiples of its 8 x 16 tile, windows clamped at every border, through one decoder pass of two images.  This profile
+    amplifies rounding, so the bar is the fp32 oracle's own distance to its fp64 evaluation."""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    K = 19
+    sd = synthetic.make_state_dict('seg', K, 6, 256, seed=31, profile='trained_like')
+    sdd = {k: v.double() for k, v in sd.items()}
+    x, noise = synthetic.make_inputs(2, h, w, 1, 256, 256, seed=32)
+    cfg = dict(task='seg', h=h, w=w, randsteps=1, timesteps=1, bit_scale=0.01, num_classes=K, accumulation=False,
+               noise_schedule='cosine', diffusion='ddim')
+    out = _engine(cfg, sd, dev, batch=2).sample(x.to(dev), noise.to(dev)).cpu()
+    out_u = _engine(cfg, sd, dev, batch=2, fused_layer=False, fused_prologue=False).sample(x.to(dev), noise.to(dev)).cpu()
+    assert torch.isfinite(out).all()
+    for b in range(2):
+        r32 = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=1, randsteps=1, bit_scale=0.01, accumulation=False)
+        r64 = O.ddim_sample_seg(x[b:b + 1].double(), noise[b].double(), sdd, timesteps=1, randsteps=1, bit_scale=0.01, accumulation=False)
+        dc = float((r32.double() - r64).abs().max())
+        scale = float(r64.abs().max())
+        for name, o in (('fused', out), ('unfused', out_u)):
+            dg = float((o[b:b + 1].double() - r64).abs().max())
+            print(f'spread offsets {h}x{w} image {b} {name}: gpu vs fp64 {dg:.3e}, fp32 oracle vs fp64 {dc:.3e} (scale {scale:.1f})')
+            assert dg <= 4 * dc + 1e-5 * scale
+
+
 # ---- the exported stand-alone DDIM update, and NaN robustness of the argmax -> LUT step -----------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize('K,ldl,rows', [(150, 160, 1000), (19, 32, 333), (256, 256, 64), (2, 32, 5)])
