@@ -20,8 +20,6 @@ import os
 import pytest
 import torch
 
-from golden_util import max_rel
-
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3

@@ -2,7 +2,6 @@
 reference classes, outputs equal to the golden vectors recorded from the reference."""
 import pytest
 import torch
-import torch.nn.functional as F
 
 import ddp_amd
 from golden_util import load_case, max_rel
