@@ -15,7 +15,7 @@ ABI_VERSION = 3
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
-FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0 = 1, 2, 4
+FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0, FLAG_GATHER_GUESS_ZERO = 1, 2, 4, 8
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
 

@@ -88,6 +88,7 @@ struct Layout {
   int b3;
   unsigned char* x0_trace;       // DDP_FLAG_RECORD_X0: (K, M) argmax class of every step
   bool fused_layer, fused_pro;   // bf16x3: persistent layer kernel / step-prologue kernel in use (cfg->flags)
+  bool guess_zero;               // DDP_FLAG_GATHER_GUESS_ZERO
   SplitW wp_x, wp_m, wp_head, wp_v[DDP_MAX_LAYERS], wp_cat[DDP_MAX_LAYERS], wp_o[DDP_MAX_LAYERS], wp_f0[DDP_MAX_LAYERS],
       wp_f1[DDP_MAX_LAYERS];
   unsigned short *q_sb, *q1_sb, *s_sb, *h_sb, *in_sb;   // in_sb: mask / x / feat staging (row-major producers)
@@ -147,7 +148,7 @@ int validate(const ddp_cfg* c) {
     set_error("bev supports at most 32 classes");
     return DDP_E_BADCFG;
   }
-  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0)) {
+  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -226,6 +227,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->x0_trace = reinterpret_cast<unsigned char*>(
       cv.take((c->flags & DDP_FLAG_RECORD_X0) && c->task == DDP_TASK_SEG ? (size_t(o->K) * o->M + 3) / 4 : 0));
   o->b3 = c->gemm_mode == DDP_GEMM_BF16X3;
+  o->guess_zero = (c->flags & DDP_FLAG_GATHER_GUESS_ZERO) != 0;
   o->fused_layer = o->b3 && !(c->flags & DDP_FLAG_UNFUSED_LAYER);
   o->fused_pro = o->fused_layer && !(c->flags & DDP_FLAG_UNFUSED_PROLOGUE);
   if (o->b3) {
@@ -518,7 +520,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
       }
       // a row-major GEMM leaves a plain value map; the layer / prologue kernels write it zero-padded
       if (own_proj) DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
-      else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
+      else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, o.py[l], o.px[l], o.guess_zero, st));
       const float* a = aff + size_t(l) * 512;
       if (fused) {
         // output_proj + LN0 + FFN + LN1 + FiLM + the next layer's value / sampling projections: one persistent kernel

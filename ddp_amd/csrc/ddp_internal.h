@@ -181,7 +181,7 @@ int launch_msda_gather(const float* value, const float* samp, float* out, int ro
 int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                           hipStream_t st);
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
-                              hipStream_t st);
+                              const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st);
 int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);
 // y[s][o] = out_act( W[o][:] . in_act(x[s][:]) + b[o] )   act: 0 none, 1 gelu(out), 2 silu(in)
 int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,

@@ -332,10 +332,13 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
 // taps of every token from LDS (ds_read_b128, the four corners as immediate offsets of one address).  Fill traffic is
 // (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.7 x 128 B per (token, head) instead of 2 KiB, and - heads pinned to XCDs, see the
 // kernel - the 1.7 x that is halo comes out of L2, not HBM.
-//   * The window of head hd is centred on the tile's MEAN sampling offset of that head (a block reduction over the
-//     tile's 4 x 128 sample points, deterministic): the reference initialises the offsets as a ring of radius 1..4 px per
-//     head (multi_scale_deform_attn.py:233-244), so the points of a head spread +-1.5 px around their mean and
-//     GL_HALO = 3 leaves 1.5 px for the learned, position- and content-dependent part.
+//   * The window of a head is centred on the tile's mean sampling offset of that head: the reference initialises the
+//     offsets as a ring of radius 1..4 px per head (multi_scale_deform_attn.py:233-244), so the points of a head spread
+//     +-1.5 px around their mean and GL_HALO = 3 leaves 1.5 px for the learned, content-dependent part.  The fill starts
+//     from the data-independent part of that mean (bias + positional term at the tile centre, read from the separable
+//     tables) and is repeated only if the tile's actual mean - a deterministic block reduction over its 4 x 128 sample
+//     points - is 2 px or more away (r03b: 0.196 -> 0.185 ms at C2, 0.387 -> 0.357 at Cityscapes size, the same with
+//     spread-out offsets).
 //   * A (token, point) whose four corners are not all inside the window is served from the zero-padded map in global
 //     memory (an 8-token group with such a point takes a lane-divergent mixed path): any offset is handled, only slower.
 //     Both paths load the same values and combine them in the same order, so the result does not depend on which one ran.
@@ -392,12 +395,13 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
 __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
-                                                                    int tiles_x, int tiles_y, int n_tiles, int m_total) {
+                                                                    int tiles_x, int tiles_y, int n_tiles, int m_total,
+                                                                    const float* __restrict__ tab_y, const float* __restrict__ tab_x,
+                                                                    int zero_guess) {
   using G = GlGeom<GL_TH, GL_TW, GL_HALO, NT>;
   constexpr int GL_WW = G::WW, GL_WH = G::WH, GL_PIX = G::PIX, GL_DMA = G::DMA, GL_WIN_B = G::WIN_B, NG = G::NG;
   __shared__ __attribute__((aligned(16))) unsigned char win[GL_WIN_B];
   __shared__ float msum[G::NW][2];
-  __shared__ int org[2];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,40 +423,6 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
   const float* simg = samp + (size_t(hd) * m_total + size_t(img) * n_tok) * 12;
   const unsigned lds_win = (unsigned)(size_t)(lds_byte_t*)win;
 
-  // ---- mean sampling offset of the head over the tile's valid tokens (thread = token x sample point)
-  {
-    static_assert(G::TOK * 4 == NT, "one (token, point) per thread");
-    const int tl = tid >> 2, p = tid & 3;
-    const int gy = y0 + tl / GL_TW, gx = x0 + tl % GL_TW;
-    float sx = 0.f, sy = 0.f;
-    if (gy < h && gx < w) {
-      const float* sp = simg + size_t(gy * w + gx) * 12 + 2 * p;
-      sx = sp[0] - float(gx);
-      sy = sp[1] - float(gy);
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      sx += __shfl_xor(sx, o, 64);
-      sy += __shfl_xor(sy, o, 64);
-    }
-    if (lane == 0) {
-      msum[wave][0] = sx;
-      msum[wave][1] = sy;
-    }
-  }
-  __syncthreads();
-  if (tid < 2) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < G::NW; ++k) v += msum[k][tid];
-    const int nv = min(GL_TW, w - x0) * min(GL_TH, h - y0) * 4;
-    v = v / float(nv);
-    v = fminf(fmaxf(v, -32768.0f), 32768.0f);              // NaN / inf coordinates: any finite origin is fine (fallback path)
-    // tid = axis: window origin in map coordinates
-    org[tid] = ((tid & 1) ? y0 : x0) + int(rintf(v)) - GL_HALO;
-  }
-  __syncthreads();
-
   const int tk = lane >> 3, q = lane & 7;
   const float xmax = float(w), ymax = float(h);
   // this lane's NG tokens (groups g: runs of 8 x-adjacent tokens of the wave's share of the tile)
@@ -468,7 +438,29 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
   const size_t img_tok = size_t(img) * n_tok;
 
   {
-    const int ox = __builtin_amdgcn_readfirstlane(org[0]), oy = __builtin_amdgcn_readfirstlane(org[1]);
+    // The window origin starts from the DATA-INDEPENDENT part of the head's mean sampling offset at the tile centre - the
+    // offset bias plus the positional term, i.e. the separable tables the layer kernel's P3 adds (k_pos_tables: tab_y (h,96),
+    // tab_x (w,96), bias folded in) - so the fill is issued at once, next to the table loads, instead of behind "sample table ->
+    // block reduction -> origin".  The tile's actual mean is then formed from the coordinates the taps need anyway, and the
+    // window is refilled only when it sits 2 px or more away from the guess (any origin is CORRECT - taps outside the window
+    // take the mixed path - the mean only decides how many do).
+    int ox, oy;
+    {
+      float gx = 0.f, gy = 0.f;
+      if (!zero_guess) {
+        const float* ty = tab_y + min(y0 + GL_TH / 2, h - 1) * 96 + hd * 8;
+        const float* tx = tab_x + min(x0 + GL_TW / 2, w - 1) * 96 + hd * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          gx += ty[2 * p] + tx[2 * p];
+          gy += ty[2 * p + 1] + tx[2 * p + 1];
+        }
+        gx = fminf(fmaxf(gx * 0.25f, -32768.0f), 32768.0f);
+        gy = fminf(fmaxf(gy * 0.25f, -32768.0f), 32768.0f);
+      }
+      ox = __builtin_amdgcn_readfirstlane(x0 + int(rintf(gx)) - GL_HALO);
+      oy = __builtin_amdgcn_readfirstlane(y0 + int(rintf(gy)) - GL_HALO);
+    }
     {
     // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
     float px_[NG], py_[NG], pw_[NG];
@@ -480,16 +472,57 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
       pw_[g] = sp[8 + (q & 3)];
     }
     // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
-    for (int k = wave; k < GL_DMA; k += G::NW) {
-      int idx = k * 8 + tk;
-      idx = idx < GL_PIX ? idx : GL_PIX - 1;
-      const int py = idx / GL_WW, px = idx - py * GL_WW;
-      const int gyp = min(max(oy + 1 + py, 0), h + 1), gxp = min(max(ox + 1 + px, 0), wp - 1);
-      const unsigned off = unsigned(gyp * wp + gxp) * 1024u + unsigned(hd * 128 + q * 16);
-      gl_dma(vimg, off, __builtin_amdgcn_readfirstlane(lds_win + unsigned(k) * 1024u));
+    auto fill = [&]() __attribute__((always_inline)) {
+      for (int k = wave; k < GL_DMA; k += G::NW) {
+        int idx = k * 8 + tk;
+        idx = idx < GL_PIX ? idx : GL_PIX - 1;
+        const int py = idx / GL_WW, px = idx - py * GL_WW;
+        const int gyp = min(max(oy + 1 + py, 0), h + 1), gxp = min(max(ox + 1 + px, 0), wp - 1);
+        const unsigned off = unsigned(gyp * wp + gxp) * 1024u + unsigned(hd * 128 + q * 16);
+        gl_dma(vimg, off, __builtin_amdgcn_readfirstlane(lds_win + unsigned(k) * 1024u));
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's DMA pieces (and its coordinate loads) landed
+    };
+    fill();
+    {
+      // the tile's mean offset from the coordinates in registers: lanes q < 4 hold one (token, point) each
+      float sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int tl = wave * (NG * 8) + g * 8 + tk;
+        if (tval[g] && q < 4) {
+          sx += px_[g] - float(x0 + tl % GL_TW);
+          sy += py_[g] - float(y0 + tl / GL_TW);
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+      }
+      if (lane == 0) {
+        msum[wave][0] = sx;
+        msum[wave][1] = sy;
+      }
+      __syncthreads();                                       // the window (guess) is complete, the partial sums are visible
+      float mx = 0.f, my = 0.f;
+#pragma unroll
+      for (int k = 0; k < G::NW; ++k) {
+        mx += msum[k][0];
+        my += msum[k][1];
+      }
+      const float inv = 1.0f / float(min(GL_TW, w - x0) * min(GL_TH, h - y0) * 4);
+      mx = fminf(fmaxf(mx * inv, -32768.0f), 32768.0f);      // NaN / inf coordinates: any finite origin is fine (mixed path)
+      my = fminf(fmaxf(my * inv, -32768.0f), 32768.0f);
+      const int oxi = __builtin_amdgcn_readfirstlane(x0 + int(rintf(mx)) - GL_HALO);
+      const int oyi = __builtin_amdgcn_readfirstlane(y0 + int(rintf(my)) - GL_HALO);
+      if (abs(oxi - ox) >= 2 || abs(oyi - oy) >= 2) {        // block-uniform: every thread summed the same eight partials
+        ox = oxi;
+        oy = oyi;
+        fill();                                              // (no wave reads the window before the barrier below)
+        __syncthreads();
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces (and its coordinate loads) landed
-    __syncthreads();
     // ---- taps
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -1425,13 +1458,13 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
   return check_launch("group_norm_nchw");
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
-                              hipStream_t st) {
+                              const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {
   constexpr int TH = 8, TW = 16, NT = GL_THREADS;
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
-  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb, n_tok, h, w,
-                     tiles_x, tiles_y, n_tiles, rows);
+  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
+                     n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");
 }

@@ -110,7 +110,8 @@ class DDPEngine:
                  feat_channels=256, bit_scale=0.01, time_difference=1, sample_range0=0.0, noise_schedule='cosine',
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
-                 weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False):
+                 weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False,
+                 gather_guess_zero=False):
         self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -150,6 +151,8 @@ class DDPEngine:
         cfg.flags = (0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE)
         if record_x0:
             cfg.flags |= _lib.FLAG_RECORD_X0
+        if gather_guess_zero:      # diagnostic: forces the LDS gather's refill branch (identical results)
+            cfg.flags |= _lib.FLAG_GATHER_GUESS_ZERO
         self.fused_layer = bool(fused_layer)
         cfg.accumulation = int(bool(accumulation))
         cfg.bit_scale, cfg.min_depth, cfg.max_depth, cfg.threshold = bit_scale, min_depth, max_depth, threshold

@@ -60,8 +60,11 @@ enum { DDP_SAMPLER_DDIM = 0, DDP_SAMPLER_DDPM = 1 };
 enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
 /* ddp_cfg.flags (diagnostics, bf16x3 engine): run the decoder layer / the head of a step as the separate tile GEMMs they
  * were fused from (identical arithmetic per contraction; used by same-box A/B runs and by the parity tests that keep
- * the unfused kernels covered).  UNFUSED_LAYER implies the unfused step head and seg tail as well. */
-enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4 };
+ * the unfused kernels covered).  UNFUSED_LAYER implies the unfused step head and seg tail as well.
+ * GATHER_GUESS_ZERO: the LDS-staged gather starts every window from a zero guess of the head's mean sampling offset instead
+ * of the mean of its offset biases, which forces its "actual mean is far from the guess: refill" branch (identical results:
+ * the window origin only decides which taps are served from LDS). */
+enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8 };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */

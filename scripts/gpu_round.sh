@@ -4,13 +4,20 @@
 # Copy what should be judged from gpurun_out/<tag>/ into profiles/ afterwards (scripts/collect_profiles.py).
 set -u
 TAG=${1:-rXX}
+QUICK=${2:-}          # "quick": headline workload only (bench, kernel stats, PMC, RCCL world-1) and the tests without C3 / C4 / C5 at full size
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "from ddp_amd import build; print(build.source_hash())" > $OUT/source_sha.txt
 # -s: the full-size parity tests and the bf16x3 arithmetic tests print the figures DESIGN.md quotes
-python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids\|^$" > $OUT/pytest_gpu.txt
-tail -3 $OUT/pytest_gpu.txt
+if [ "$QUICK" = quick ]; then
+  KSEL='-k not(c3_cityscapes or c4_kitti or c5_bev)'
+else
+  KSEL=
+fi
+PYTEST_ORDER="python -m pytest tests -m gpu -q -s"
+run_tests() { $PYTEST_ORDER ${KSEL:+"$KSEL"} 2>&1 | grep -v "amdgpu.ids\|^$" > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt; }
+[ "$QUICK" = quick ] || run_tests
 python bench.py --steps 10 --warmup 2 --next-rows > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json; tail -3 $OUT/bench.err
 REPO=$PWD
@@ -25,14 +32,16 @@ timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RE
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_wr -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_wr.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma -o ddp -- $BENCH > $REPO/$OUT/pmc_mfma.log 2>&1
 # the other BASELINE configurations (per-GPU shards): kernel stats + MFMA-busy counters each
-for wl in city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200; do
+WLS="city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200"
+[ "$QUICK" = quick ] && WLS=
+for wl in $WLS; do
   B2="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --workload $wl"
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_$wl -o ddp -- $B2 > $REPO/$OUT/prof_$wl.log 2>&1
   timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma_$wl -o ddp -- $B2 > $REPO/$OUT/pmc_mfma_$wl.log 2>&1
 done
 cd $REPO
 # the other BASELINE configurations as plain bench lines: throughput, roofline, CPU baseline and full-size parity of one image
-for wl in city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200; do
+for wl in $WLS; do
   timeout 400 python bench.py --workload $wl --steps 3 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   tail -1 $OUT/bench_$wl.json | cut -c1-200
 done
@@ -44,3 +53,5 @@ tail -1 $OUT/force_dist_rccl_world1.json | cut -c1-300
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -30 "$f"
 python scripts/collect_profiles.py $TAG --print-only
+# quick mode: the measurements first, the tests last
+[ "$QUICK" = quick ] && run_tests

@@ -133,6 +133,11 @@ def test_c2_ade_8x512x1024_k3(dev):
                      accumulation=True, device=dev)
     assert torch.equal(eng0.sample(x.to(dev), noise.to(dev)).cpu(), out)
     del eng0
+    # so is the gather's window origin: starting every window from a zero guess (refill branch) gives the same bits
+    engz = DDPEngine(sd, 'seg', h=h, w=w, batch=B, randsteps=1, timesteps=K, num_classes=ncls, bit_scale=0.01,
+                     accumulation=True, device=dev, gather_guess_zero=True)
+    assert torch.equal(engz.sample(x.to(dev), noise.to(dev)).cpu(), out)
+    del engz
     for b, free in ((0, True), (5, True)):
         _seg_parity_with_decisions('C2', eng, out, x, noise, sd, b, K, True, free)
     eng1 = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=1, num_classes=ncls, bit_scale=0.01,

@@ -161,7 +161,9 @@ def test_head_forward_trace(dev, name):
 # f32-input MFMA engine (include/ddp_mi355x.h DDP_GEMM_*, DDP_FLAG_*)
 VARIANTS = {'bf16x3': dict(gemm='bf16x3'), 'f32': dict(gemm='f32'),
             'bf16x3-unfused-layer': dict(gemm='bf16x3', fused_layer=False),
-            'bf16x3-unfused-prologue': dict(gemm='bf16x3', fused_prologue=False)}
+            'bf16x3-unfused-prologue': dict(gemm='bf16x3', fused_prologue=False),
+            # the LDS gather's "actual mean offset is far from the guess: refill the window" branch (DDP_FLAG_GATHER_GUESS_ZERO)
+            'bf16x3-gather-refill': dict(gemm='bf16x3', gather_guess_zero=True)}
 
 
 @pytest.mark.parametrize('variant', sorted(VARIANTS))
