@@ -41,6 +41,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     'ade_swin_t_k3_8x512x1024': dict(task='seg', batch=8, h=128, w=256, timesteps=3, randsteps=1, num_classes=150,
                                      bit_scale=0.01, accumulation=True, num_layers=6),
+    # what each of 8 GPUs gets from configs[1] under STRONG scaling (the reference's own protocol is one image per call,
+    # tools/test.py:214-219): 256 tiles of 128 tokens = one tile per CU of the persistent layer kernel
+    'ade_swin_t_k3_1x512x1024': dict(task='seg', batch=1, h=128, w=256, timesteps=3, randsteps=1, num_classes=150,
+                                     bit_scale=0.01, accumulation=True, num_layers=6),
     'ade_swin_t_k1_1x512x512': dict(task='seg', batch=1, h=128, w=128, timesteps=1, randsteps=1, num_classes=150,
                                     bit_scale=0.01, accumulation=True, num_layers=6),
     # the per-GPU shards of BASELINE.json configs[2..4] (not the headline metric: no cpu_baseline / parity leg here,
@@ -56,6 +60,9 @@ WORKLOADS = {
                                     bev_input_scope=[[-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8]],
                                     bev_output_scope=[[-50, 50, 0.5], [-50, 50, 0.5]]),
 }
+# --scaling strong: the configuration's TOTAL batch (BASELINE.json configs[1..4]) is split over the ranks
+TOTAL_BATCH = {'ade_swin_t_k3_8x512x1024': 8, 'city_swin_l_k10_4x1024x2048': 32, 'kitti_depth_k20_16x352x1216': 16,
+               'bev_fusion_k3_8x200x200': 64}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles/SIMD)
 B3_PRODUCTS = 6                    # bf16 MFMA products per fp32-equivalent product in the bf16x3 engine
@@ -150,6 +157,160 @@ def swin_t_standin_ms(B, H, W, dev, timed):
     return ms, 2 * macs / 1e9
 
 
+class PowerSampler:
+    """Package power (W) and shader clock (MHz) of one GPU, sampled by a background thread while the loop runs.
+    Source: the amdgpu hwmon files in sysfs (power1_average / power1_input in microwatts, freq1_input in Hz) - a plain
+    file read, so 20 ms sampling costs nothing; falls back to `rocm-smi --json` (slower, ~0.3 s per sample).  The part runs
+    this loop at its package power cap, so throughput is set by energy per image: the line carries
+    ``joules_per_image`` next to the roofline fraction."""
+
+    def __init__(self, index=0, period=0.02):
+        import glob
+        self.period = period
+        self.samples = []
+        self.power_file = self.clk_file = None
+        self.cap_w = None
+        self.source = None
+        cards = []
+        for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+            for name in ('power1_average', 'power1_input'):
+                if os.path.exists(os.path.join(hw, name)):
+                    cards.append((hw, name))
+                    break
+        if cards:
+            hw, name = cards[min(index, len(cards) - 1)]
+            self.power_file = os.path.join(hw, name)
+            self.clk_file = os.path.join(hw, 'freq1_input') if os.path.exists(os.path.join(hw, 'freq1_input')) else None
+            try:
+                self.cap_w = int(open(os.path.join(hw, 'power1_cap')).read()) / 1e6
+            except Exception:
+                pass
+            self.source = 'sysfs hwmon ' + self.power_file
+        else:
+            import shutil
+            self.smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+            if os.path.exists(self.smi):
+                self.source = 'rocm-smi --showpower --showclocks --json'
+                self.period = 0.05
+        self._stop = False
+        self._thread = None
+
+    def _read(self):
+        if self.power_file:
+            try:
+                pw = int(open(self.power_file).read()) / 1e6
+                clk = int(open(self.clk_file).read()) / 1e6 if self.clk_file else None
+                return pw, clk
+            except Exception:
+                return None
+        import re
+        import subprocess
+        try:
+            txt = subprocess.run([self.smi, '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=5).stdout
+            card = next(iter(json.loads(txt).values()))
+            pw = clk = None
+            for k, v in card.items():
+                if 'Power' in k and '(W)' in k and pw is None:
+                    pw = float(v)
+                if k.startswith('sclk clock speed'):
+                    m = re.search(r'(\d+)', str(v))
+                    clk = float(m.group(1)) if m else None
+            return (pw, clk) if pw is not None else None
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            r = self._read()
+            if r is not None:
+                self.samples.append((time.perf_counter(),) + r)
+            time.sleep(self.period)
+
+    def start(self):
+        if self.source is None:
+            return
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=10)
+
+    def summary(self, t_from, t_to):
+        """mean / max over the samples taken inside [t_from, t_to] (the first 0.3 s of the loop are left out by the caller:
+        the power controller needs that long to settle)."""
+        ss = [x for x in self.samples if t_from <= x[0] <= t_to]
+        if not ss:
+            return None
+        pw = [x[1] for x in ss]
+        ck = [x[2] for x in ss if x[2] is not None]
+        return {'power_w': round(sum(pw) / len(pw), 1), 'power_w_max': round(max(pw), 1),
+                'sclk_mhz': round(sum(ck) / len(ck), 0) if ck else None, 'sclk_mhz_min': round(min(ck), 0) if ck else None,
+                'samples': len(ss), 'power_cap_w': self.cap_w, 'source': self.source}
+
+
+def size_stream(n_sizes, sd, wl, dev):
+    """The reference's test protocol on the plugin surface: one image per call, a new (h, w) almost every call.  Returns the
+    streaming rate and the cost of a geometry change relative to the loop time of the same image at a fixed geometry."""
+    import random
+    import ddp_amd
+    enc = dict(type='DetrTransformerEncoder', num_layers=wl['num_layers'],
+               transformerlayers=dict(type='BaseTransformerLayer', use_time_mlp=True,
+                                      attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256, num_levels=1, num_heads=8, dropout=0.),
+                                      ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, ffn_drop=0., act_cfg=dict(type='GELU')),
+                                      operation_order=('self_attn', 'norm', 'ffn', 'norm')))
+    model = ddp_amd.build_segmentor(dict(
+        type='DDP', timesteps=wl['timesteps'], bit_scale=wl['bit_scale'], accumulation=wl['accumulation'], randsteps=wl['randsteps'],
+        decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0], dropout_ratio=0.,
+                         num_classes=wl['num_classes'], align_corners=False, num_feature_levels=1, encoder=enc,
+                         positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True, offset=-0.5)),
+        train_cfg=dict(), test_cfg=dict(mode='whole')))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    # ADE20K test images: Resize(img_scale=(2048, 512), keep_ratio=True) (configs/_base_/datasets/ade20k.py:23): short side 512
+    # px = 128 tokens, aspect ratio 1 .. 2 either way round
+    rng = random.Random(0)
+    sizes = []
+    while len(sizes) < n_sizes:
+        lng = (int(512 * rng.uniform(1.0, 2.0)) + 3) // 4
+        hw = (128, lng) if rng.random() < 0.7 else (lng, 128)
+        if hw not in sizes:
+            sizes.append(hw)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    feats = [(torch.randn(1, 256, h, w, generator=g).to(dev), torch.randn(1, wl['randsteps'], 256, h, w, generator=g).to(dev)) for h, w in sizes]
+
+    def stream():
+        for x, nz in feats:
+            model.ddim_sample(x, noise=nz)
+    stream()                                   # first pass: engine, packed weights, workspace growth
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stream()
+    torch.cuda.synchronize()
+    t_stream = time.perf_counter() - t0
+    # the same images with the geometry held: per size 1 untimed + 3 timed calls
+    t_fixed = 0.0
+    for x, nz in feats:
+        model.ddim_sample(x, noise=nz)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            model.ddim_sample(x, noise=nz)
+        torch.cuda.synchronize()
+        t_fixed += (time.perf_counter() - t1) / 3
+    eng = next(iter(model._engine_cache.values()))
+    return {'sizes': n_sizes, 'tokens_min_max': [min(h * w for h, w in sizes), max(h * w for h, w in sizes)],
+            'stream_ms_per_image': round(t_stream / n_sizes * 1e3, 3), 'fixed_geometry_ms_per_image': round(t_fixed / n_sizes * 1e3, 3),
+            'geometry_change_ms': round((t_stream - t_fixed) / n_sizes * 1e3, 3),
+            'geometry_change_overhead': round((t_stream - t_fixed) / t_fixed, 4), 'stream_images_per_s': round(n_sizes / t_stream, 2),
+            'engines_built': len(model._engine_cache), 'geometry_changes': eng.geometry_changes,
+            'note': 'registered DDP segmentor, ddim_sample(x) with b = 1 and a different ADE20K-like (h, w) every call; features '
+                    'resident in HBM; geometry change = DDPEngine.set_geometry (positional tables + workspace carve; weights, '
+                    'split planes, weight streams and LUTs are kept)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -159,6 +320,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2, help='images timed on the CPU oracle (bounded sample)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="weak (default): the workload's batch per GPU.  strong: the configuration's TOTAL batch "
+                         '(BASELINE.json) is split over the ranks (configs[1]: 8 images -> 1 per GPU at 8 GPUs)')
+    ap.add_argument('--size-stream', type=int, default=0, metavar='N',
+                    help="also time the reference's own test protocol (tools/test.py:214-219): N single-image calls of the "
+                         'registered DDP segmentor, every call a different ADE20K-like map size (short side 128 tokens, '
+                         'keep-ratio long side); reported under "size_stream", never part of value')
+    ap.add_argument('--no-power', action='store_true', help='skip the power / clock sampling leg')
+    ap.add_argument('--power-seconds', type=float, default=2.0, help='length of the back-to-back loop the power leg samples')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the process-group code path (RCCL init, weight broadcast, barrier, MAX all_reduce) even at world size 1')
     ap.add_argument('--next-rows', action='store_true',
@@ -188,6 +358,20 @@ def main():
 
     wl = WORKLOADS[args.workload]
     B, h, w, K = wl['batch'], wl['h'], wl['w'], wl['timesteps']
+    # strong scaling: a rank's share of the configuration's total batch, processed in calls of at most the workload's
+    # batch (images are independent: the reference's sampler is one image per call anyway)
+    calls_per_step = 1
+    if args.scaling == 'strong':
+        if args.workload not in TOTAL_BATCH:
+            raise SystemExit(f'bench.py: --scaling strong needs a BASELINE configuration, one of {sorted(TOTAL_BATCH)}')
+        total = TOTAL_BATCH[args.workload]
+        if total % world:
+            raise SystemExit(f'bench.py: total batch {total} of {args.workload} does not split over {world} ranks')
+        share = total // world
+        B = min(share, wl['batch'])
+        if share % B:
+            raise SystemExit(f'bench.py: per-rank share {share} is not a multiple of the call batch {B}')
+        calls_per_step = share // B
     # frozen weights: generated on rank 0, replicated by ONE RCCL broadcast of the packed blob
     task = wl['task']
     cx = wl.get('feat_channels', 256)
@@ -220,12 +404,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step():
+        for _ in range(calls_per_step):
+            eng.sample(dx, dn, out=out)
+
     for _ in range(args.warmup):
-        eng.sample(dx, dn, out=out)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.sample(dx, dn, out=out)
+        one_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
@@ -233,7 +421,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    images_per_s = B * world * args.steps / elapsed
+    images_per_s = B * calls_per_step * world * args.steps / elapsed
+
+    # ---- power leg (rank 0): the same loop back to back for a couple of seconds with package power and shader clock
+    # sampled beside it; also gives the SUSTAINED rate (the timed region above is a fraction of a second)
+    power = None
+    if rank == 0 and not args.no_power:
+        ps = PowerSampler(local_rank)
+        if ps.source is not None:
+            ps.start()
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            n_steps = 0
+            while True:
+                one_step()
+                n_steps += 1
+                if n_steps % 4 == 0:
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - tp0 >= args.power_seconds:
+                        break
+            torch.cuda.synchronize()
+            tp1 = time.perf_counter()
+            ps.stop()
+            power = ps.summary(tp0 + min(0.3, 0.3 * (tp1 - tp0)), tp1)
+            if power is not None:
+                sustained = B * calls_per_step * n_steps / (tp1 - tp0)
+                power['loop_seconds'] = round(tp1 - tp0, 2)
+                power['sustained_images_per_s'] = round(sustained, 2)
+                power['joules_per_image'] = round(power['power_w'] / sustained, 3)
+    if dist_on:
+        dist.barrier()
 
     # ---- roofline leg: HIP events around every launch of the dominant kernel, same workload ----------
     roofline = None
@@ -304,7 +521,10 @@ def main():
         except Exception as e:
             roofline['traffic_source'] = str(e)[:120]
         # whole-loop dense-contraction rate for context
-        loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes'], cx) * float(M) * K
+        loop_flops = flops_per_token_step(wl['num_layers'], wl['num_classes'], cx) * float(M) * K * calls_per_step
+        if power is not None:
+            roofline['power_w'] = power['power_w']
+            roofline['sclk_mhz'] = power['sclk_mhz']
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
         roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
 
@@ -345,6 +565,10 @@ def main():
                      'note': 'same batch; backbone = torch-ROCm fp32 stand-in with the dense layers of Swin-T (the backbone itself '
                              'is out of scope and stays PyTorch-ROCm); neck inputs = synthetic backbone levels (Swin-T channels)'}
 
+    stream_res = None
+    if args.size_stream > 0 and rank == 0 and task == 'seg':
+        stream_res = size_stream(args.size_stream, sd, wl, dev)
+
     # ---- CPU baseline + parity (rank 0, N=1) ---------------------------------------------------------
     cpu = None
     parity = None
@@ -356,13 +580,13 @@ def main():
         n_img = max(1, min(args.cpu_images if headline else 1, B))
         r = wl['randsteps']
 
-        def oracle_run(b, steps=K, dtype=torch.float32, accumulation=wl['accumulation'], x0_index=None):
+        def oracle_run(b, steps=K, dtype=torch.float32, accumulation=wl['accumulation'], x0_index=None, decisions=None):
             """the reference's sampler for ONE image of the batch (the reference loop is b = 1), restated on the CPU"""
             xs, ns = x[b:b + 1].to(dtype), noise[b].to(dtype)
             sdd = sd if dtype == torch.float32 else {k: v.to(dtype) for k, v in sd.items()}
             if task == 'seg':
                 return O.ddim_sample_seg(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'], accumulation=accumulation,
-                                         x0_index=x0_index)
+                                         x0_index=x0_index, decisions=decisions)
             if task == 'depth':
                 return O.sample_depth(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'])
             return O.ddim_sample_bev(xs, ns, sdd, timesteps=steps, randsteps=r, bit_scale=wl['bit_scale'],
@@ -371,12 +595,15 @@ def main():
         gpu_out = out.cpu()
         tcpu = 0.0
         worst, agree, bad_px = 0.0, 1.0, 0
+        ref0, dec0, worst0 = None, [], 0.0
         for b in range(n_img):
             t1 = time.perf_counter()
-            ref = oracle_run(b)
+            ref = oracle_run(b, decisions=dec0 if (b == 0 and task == 'seg') else None)
             tcpu += time.perf_counter() - t1
             rel = (gpu_out[b:b + 1] - ref).abs().amax(1) / ref.abs().max()
             worst = max(worst, float(rel.max()))
+            if b == 0:
+                ref0, worst0 = ref, float(rel.max())
             bad_px += int((rel > 1e-4).sum())
             if task == 'seg':
                 agree = min(agree, float((gpu_out[b:b + 1].argmax(1) == ref.argmax(1)).float().mean()))
@@ -402,6 +629,18 @@ def main():
                 del engd
             except Exception as e:
                 parity['max_rel_decisions_fed'] = {'error': str(e)[:200]}
+        # (seg) the yardstick for the free-running figure: the REFERENCE restated twice - grid_sample core (its CPU path) vs
+        # explicit-taps core (the arithmetic of mmcv's compiled kernel, its GPU path), and fp32 vs fp64 - drifts from
+        # itself by this much on the same image when each run takes its own argmax (oracle.reference_drift_seg)
+        if task == 'seg' and r == 1 and K > 1:
+            try:
+                dr = O.reference_drift_seg(x[:1], noise[0], sd, timesteps=K, accumulation=wl['accumulation'], bit_scale=wl['bit_scale'],
+                                           base=ref0, base_decisions=dec0)
+                parity['free_running_image0'] = worst0
+                parity['reference_vs_reference'] = {'max_rel': dr['ref_vs_ref'], 'variants': dr['variants']}
+                parity['free_running_within_2x_reference_drift'] = bool(worst0 <= max(1e-3, 2 * dr['ref_vs_ref']))
+            except Exception as e:
+                parity['reference_vs_reference'] = {'error': str(e)[:200]}
         # The K-step output feeds argmax back into the next step, so ONE near-tie pixel that rounds the other way moves
         # a ~20x20 neighbourhood by 1e-4..1e-3 (SURVEY.md §7 hard part 1) in any fp32 implementation.  The feedback-free
         # figure: single-step scores (K=1, no accumulation) of image 0 against an fp64 evaluation of the oracle, beside
@@ -430,18 +669,19 @@ def main():
                       else f'images/s at {K} DDIM steps ({args.workload})',
             'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': n_ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
+            'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32 (bf16x3-split MFMA products, fp32 accumulate)' if eng.gemm == 'bf16x3' else 'f32',
             'data': 'synthetic',
             'config': {'workload': args.workload + (' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
                                                     'per GPU; x (8,256,128,256), random-init weights)'
                                                     if args.workload == 'ade_swin_t_k3_8x512x1024' else
                                                     f' ({task} decoder, batch {B} per GPU, x ({B},{cx},{h},{w}), random-init weights)'),
-                       'images_per_gpu_per_step': B, 'ddim_steps': K, 'tokens_per_image': h * w,
+                       'images_per_gpu_per_step': B * calls_per_step, 'images_per_call': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
             'images_per_s_per_gpu': round(images_per_s / world, 3),
-            'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows,
+            'roofline': roofline, 'power': power, 'joules_per_image': (power or {}).get('joules_per_image'),
+            'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows, 'size_stream': stream_res,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

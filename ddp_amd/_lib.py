@@ -10,7 +10,7 @@ from . import build as _build
 
 MAX_LAYERS = 12
 MAX_STEPS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
@@ -67,7 +67,15 @@ class DdpFcnConv(C.Structure):
                 ('bn_eps', C.c_float), ('time_w', _fp), ('time_b', _fp)]
 
 
-EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_prepare', 'ddp_sample',
+class DdpSegAug(C.Structure):
+    _fields_ = [('d_scores', _fp), ('h', C.c_int32), ('w', C.c_int32), ('img_h', C.c_int32), ('img_w', C.c_int32),
+                ('crop_h', C.c_int32), ('crop_w', C.c_int32), ('flip', C.c_int32)]
+
+
+MAX_AUGS = 16
+
+EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_query_const_workspace', 'ddp_prepare',
+           'ddp_prepare_geometry', 'ddp_sample', 'ddp_msda_forward_lds_workspace', 'ddp_msda_forward_lds', 'ddp_seg_aug_postprocess',
            'ddp_x0_trace', 'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
            'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
@@ -98,6 +106,12 @@ def load(path=None):
     lib.ddp_abi_version.restype = C.c_int
     lib.ddp_query_workspace.argtypes = [C.POINTER(DdpCfg), C.POINTER(C.c_size_t)]
     lib.ddp_prepare.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp]
+    lib.ddp_query_const_workspace.argtypes = [C.POINTER(DdpCfg), C.POINTER(C.c_size_t)]
+    lib.ddp_prepare_geometry.argtypes = [C.POINTER(DdpCfg), _fp, _fp]
+    lib.ddp_msda_forward_lds_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_msda_forward_lds.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
+    lib.ddp_seg_aug_postprocess.argtypes = [C.POINTER(DdpSegAug), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp,
+                                            _fp]
     lib.ddp_sample.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp, _fp, _fp,
                                _fp, _fp]
     lib.ddp_x0_trace.argtypes = [C.POINTER(DdpCfg), _fp, C.POINTER(C.c_void_p)]

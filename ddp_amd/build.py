@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libddp_mi355x.so')
 SOURCES = ['ddp_api.hip', 'ddp_gemm.hip', 'ddp_gemm_bf16.hip', 'ddp_kernels.hip']
-HEADERS = ['ddp_internal.h', 'gemm_f32.h', 'gemm_bf16x3.h', 'layer_bf16x3.h', os.path.join('..', '..', 'include', 'ddp_mi355x.h')]
+HEADERS = ['exports.map', 'ddp_internal.h', 'gemm_f32.h', 'gemm_bf16x3.h', 'layer_bf16x3.h', os.path.join('..', '..', 'include', 'ddp_mi355x.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 
 
@@ -54,7 +54,8 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + os.path.join(CSRC, 'exports.map'),
+           '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -40,6 +40,7 @@ struct Prof {
   unsigned char rec_tag[PROF_MAX];
   float ms[PROF_MAX];
   bool created = false;
+  bool resolved = false;             // ddp_profile_end ran for the records in ms[] (cleared by ddp_profile_begin)
 } g_prof;
 }  // namespace
 
@@ -104,6 +105,7 @@ struct Layout {
   float* tail4_bias;                                    //             conv_seg bias | layer 0's value_proj bias at [1024, 1280)
   unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
   float* tail_bias;                                     //           conv_seg bias, zero padded
+  size_t const_bytes;   // region A (model constants): a prefix of the workspace that does not depend on the geometry
   size_t total;
 };
 
@@ -187,7 +189,9 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->M0 = size_t(o->R) * o->N;
   o->M = size_t(o->R) * o->Nh;
   o->ldl = c->task == DDP_TASK_SEG ? ((o->Kc + 31) / 32) * 32 : 32;
-  // constants
+  // ---- region A: MODEL constants.  Sizes depend on (task, K, L, K_cls, Cx, gemm_mode) only - not on batch, r or the map
+  // size - so this prefix of the workspace stays valid when only the geometry changes (ddp_prepare_geometry): the
+  // reference's own test protocol is one image per call with a new (h, w) almost every call (tools/test.py:214-219)
   o->tin = cv.take(DDP_MAX_STEPS);
   o->u = cv.take(size_t(o->K) * DDP_SINU_FEATS);
   o->hid = cv.take(size_t(o->K) * DDP_TIME_DIM);
@@ -202,34 +206,12 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     const bool on = l < o->L;
     o->wcat[l] = on ? cv.take(96 * 256) : nullptr;
     o->bcat[l] = on ? cv.take(96) : nullptr;
-    o->py[l] = on ? cv.take(size_t(o->hh) * 96) : nullptr;
-    o->px[l] = on ? cv.take(size_t(o->wh) * 96) : nullptr;
   }
-  // activations
-  o->xproj = cv.take(size_t(o->B) * o->N * 256);
-  o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
-  o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
-  o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
-  const size_t Mp = (o->M + 255) / 256 * 256;        // fragment-major buffers hold whole block tiles (128 / 256 tokens)
-  o->q = cv.take(Mp * 256);                          // fragment-major
-  o->q1 = cv.take(Mp * 256);                         // fragment-major
-  o->v = cv.take(o->M * 256);                        // row-major (gather taps want a head's 128 B contiguous)
-  o->s = cv.take(o->M * 256);                        // row-major
-  o->samp = cv.take(o->M * DDP_SAMP_STRIDE);
-  size_t hb = Mp * DDP_FFN;                          // fragment-major
-  const size_t xt = size_t(o->B) * o->N * o->Cx;
-  if (xt > hb) hb = xt;
-  o->hbuf = cv.take(hb);
-  o->xtok = o->hbuf;  // x in token-major form is dead once xproj exists
-  o->logits = cv.take(o->M * o->ldl);
-  o->prob = cv.take(o->M * o->ldl);
-  o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
-  o->x0_trace = reinterpret_cast<unsigned char*>(
-      cv.take((c->flags & DDP_FLAG_RECORD_X0) && c->task == DDP_TASK_SEG ? (size_t(o->K) * o->M + 3) / 4 : 0));
   o->b3 = c->gemm_mode == DDP_GEMM_BF16X3;
   o->guess_zero = (c->flags & DDP_FLAG_GATHER_GUESS_ZERO) != 0;
   o->fused_layer = o->b3 && !(c->flags & DDP_FLAG_UNFUSED_LAYER);
   o->fused_pro = o->fused_layer && !(c->flags & DDP_FLAG_UNFUSED_PROLOGUE);
+  const bool segp = c->task == DDP_TASK_SEG;
   if (o->b3) {
     // split weights: 3 bf16 per fp32 = 1.5 floats per element
     auto takew = [&](size_t rows, size_t K) {
@@ -252,6 +234,50 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
       o->wstream[l] = reinterpret_cast<unsigned char*>(cv.take(b3_layer_stream_bytes() / sizeof(float)));
       o->bias_ext[l] = cv.take(size_t(b3_layer_bias_floats()));
     }
+    o->tail_stream = reinterpret_cast<unsigned char*>(cv.take(size_t(8) * 48 * 1024 / sizeof(float)));
+    o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
+    o->pro_stream = reinterpret_cast<unsigned char*>(cv.take(b3_prologue_stream_bytes() / sizeof(float)));
+    o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
+    o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
+    o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
+    o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : 0);
+  } else {
+    o->tail_stream = nullptr;
+    o->tail_bias = nullptr;
+    o->pro_stream = nullptr;
+    o->pro_bias = nullptr;
+    o->tail4_stream = nullptr;
+    o->tail4_bias = nullptr;
+    o->tlut = nullptr;
+  }
+  o->const_bytes = cv.off * sizeof(float);
+  // ---- region B: everything that depends on the geometry (batch, r, map size): positional tables, activations
+  for (int l = 0; l < DDP_MAX_LAYERS; ++l) {
+    const bool on = l < o->L;
+    o->py[l] = on ? cv.take(size_t(o->hh) * 96) : nullptr;
+    o->px[l] = on ? cv.take(size_t(o->wh) * 96) : nullptr;
+  }
+  o->xproj = cv.take(size_t(o->B) * o->N * 256);
+  o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
+  o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
+  o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
+  const size_t Mp = (o->M + 255) / 256 * 256;        // fragment-major buffers hold whole block tiles (128 / 256 tokens)
+  o->q = cv.take(Mp * 256);                          // fragment-major
+  o->q1 = cv.take(Mp * 256);                         // fragment-major
+  o->v = cv.take(o->M * 256);                        // row-major (gather taps want a head's 128 B contiguous)
+  o->s = cv.take(o->M * 256);                        // row-major
+  o->samp = cv.take(o->M * DDP_SAMP_STRIDE);
+  size_t hb = Mp * DDP_FFN;                          // fragment-major
+  const size_t xt = size_t(o->B) * o->N * o->Cx;
+  if (xt > hb) hb = xt;
+  o->hbuf = cv.take(hb);
+  o->xtok = o->hbuf;  // x in token-major form is dead once xproj exists
+  o->logits = cv.take(o->M * o->ldl);
+  o->prob = cv.take(o->M * o->ldl);
+  o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
+  o->x0_trace = reinterpret_cast<unsigned char*>(
+      cv.take((c->flags & DDP_FLAG_RECORD_X0) && c->task == DDP_TASK_SEG ? (size_t(o->K) * o->M + 3) / 4 : 0));
+  if (o->b3) {
     auto takesb = [&](size_t rows, size_t C) {       // SB: 6 bytes per element, rows padded to 256
       const size_t rp = (rows + 255) / 256 * 256;
       return reinterpret_cast<unsigned short*>(cv.take((rp * C * 3 + 1) / 2));
@@ -260,14 +286,6 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     // last map would otherwise be whatever follows in the workspace (0 x NaN = NaN)
     o->vpad_floats = (size_t(o->R) * (o->hh + 2) + 1) * (o->wh + 2) * 256 + 256;
     o->vpad = cv.take(o->vpad_floats);
-    o->tail_stream = reinterpret_cast<unsigned char*>(cv.take(size_t(8) * 48 * 1024 / sizeof(float)));
-    o->tail_bias = cv.take(size_t(b3_layer_bias_floats()));
-    o->pro_stream = reinterpret_cast<unsigned char*>(cv.take(b3_prologue_stream_bytes() / sizeof(float)));
-    o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
-    const bool segp = c->task == DDP_TASK_SEG;
-    o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
-    o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
-    o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : 0);
     o->ubuf = cv.take(segp ? (o->M + 255) / 256 * 256 * 256 : 0);
     o->q_sb = takesb(o->M, 256);
     o->q1_sb = takesb(o->M, 256);
@@ -283,13 +301,6 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->q_sb = o->q1_sb = o->s_sb = o->h_sb = o->in_sb = nullptr;
     o->vpad = nullptr;
     o->vpad_floats = 0;
-    o->tail_stream = nullptr;
-    o->tail_bias = nullptr;
-    o->pro_stream = nullptr;
-    o->pro_bias = nullptr;
-    o->tail4_stream = nullptr;
-    o->tail4_bias = nullptr;
-    o->tlut = nullptr;
     o->ubuf = nullptr;
   }
   o->total = cv.off * sizeof(float);
@@ -375,8 +386,20 @@ int fold_affine_dev(const ddp_weights* w, int L, int S, const float* film, float
   return DDP_OK;
 }
 
-// constants that do not depend on the schedule
-int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipStream_t st) {
+// geometry-dependent constants (region B): separable positional tables of every layer (from the packed offset / attention
+// projections of region A) and the zero border of the padded value maps
+int prepare_geometry(const Layout& o, hipStream_t st) {
+  for (int l = 0; l < o.L; ++l) DDP_TRY(launch_pos_tables(o.wcat[l], o.bcat[l], o.py[l], o.px[l], o.hh, o.wh, st));
+  // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
+  if (o.b3 && hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
+    set_error("hipMemsetAsync(vpad) failed");
+    return DDP_E_LAUNCH;
+  }
+  return DDP_OK;
+}
+
+// model constants that do not depend on the schedule (region A)
+int prepare_model(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipStream_t st) {
   DDP_TRY(launch_pack_cols(w->transform_w, o.Cx + o.Cm, 0, 256, o.Cx, o.wx, st));
   DDP_TRY(launch_pack_cols(w->transform_w, o.Cx + o.Cm, o.Cx, 256, o.Cm, o.wm, st));
   if (c->task == DDP_TASK_SEG) DDP_TRY(launch_build_lut(w->embedding, o.lut, o.Kc + 1, c->bit_scale, st));
@@ -385,7 +408,6 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
     const ddp_layer_weights& lw = w->layers[l];
     DDP_TRY(launch_pack_rows(lw.sampling_offsets_w, 64, lw.attention_weights_w, 32, o.wcat[l], 256, st));
     DDP_TRY(launch_pack_rows(lw.sampling_offsets_b, 64, lw.attention_weights_b, 32, o.bcat[l], 1, st));
-    DDP_TRY(launch_pos_tables(o.wcat[l], o.bcat[l], o.py[l], o.px[l], o.hh, o.wh, st));
   }
   if (o.b3) {
     auto wr = [](const SplitW& w) { return const_cast<unsigned short*>(w.p); };
@@ -441,11 +463,6 @@ int prepare_static(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipS
         set_error("prologue bias copy failed");
         return DDP_E_LAUNCH;
       }
-    }
-    // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
-    if (hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
-      set_error("hipMemsetAsync(vpad) failed");
-      return DDP_E_LAUNCH;
     }
     // layer-kernel weight streams: [Wo: 8 wide stages][16 x (fc1 tall, tall, fc2 wide, wide)][next Wv: 8 tall][next Wcat: 2 tall + 1 split-K]
     for (int l = 0; l < o.L; ++l) {
@@ -601,6 +618,7 @@ int ddp_profile_begin(int tag) {
   }
   g_prof.n = 0;
   g_prof.tag = tag;
+  g_prof.resolved = false;
   return DDP_OK;
 }
 
@@ -618,6 +636,7 @@ int ddp_profile_end(float* total_ms, int* launches) {
     g_prof.ms[i] = ms;
     tot += ms;
   }
+  g_prof.resolved = true;
   if (total_ms) *total_ms = tot;
   if (launches) *launches = n;
   return DDP_OK;
@@ -625,6 +644,14 @@ int ddp_profile_end(float* total_ms, int* launches) {
 
 int ddp_profile_read(int tag, float* total_ms, int* launches) {
   // after ddp_profile_end: the share of one call site in the records of the last session
+  if (tag < 0 || tag >= TAG_COUNT) {
+    set_error("profile: unknown tag %d", tag);
+    return DDP_E_BADCFG;
+  }
+  if (!g_prof.resolved) {
+    set_error("profile: no finished session (call ddp_profile_end first)");
+    return DDP_E_BADCFG;
+  }
   float tot = 0.f;
   int cnt = 0;
   for (int i = 0; i < g_prof.n; ++i)
@@ -661,13 +688,34 @@ int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   Layout o;
   carve(cfg, static_cast<float*>(d_workspace), &o);
-  DDP_TRY(prepare_static(cfg, weights, o, st));
+  DDP_TRY(prepare_model(cfg, weights, o, st));
+  DDP_TRY(prepare_geometry(o, st));
   float tin[DDP_MAX_STEPS];
   for (int s = 0; s < o.K; ++s) tin[s] = steps[s].time_in;
   DDP_TRY(launch_write_floats(tin, o.K, o.tin, st));
   DDP_TRY(time_embed_dev(weights, o.L, o.tin, o.K, o.u, o.hid, o.temb, o.film, st));
   DDP_TRY(fold_affine_dev(weights, o.L, o.K, o.film, o.aff, st));
   return DDP_OK;
+}
+
+int ddp_query_const_workspace(const ddp_cfg* cfg, size_t* bytes) {
+  DDP_TRY(validate(cfg));
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  Layout o;
+  carve(cfg, nullptr, &o);
+  *bytes = o.const_bytes;
+  return DDP_OK;
+}
+
+int ddp_prepare_geometry(const ddp_cfg* cfg, void* d_workspace, void* stream) {
+  DDP_TRY(validate(cfg));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  Layout o;
+  carve(cfg, static_cast<float*>(d_workspace), &o);
+  return prepare_geometry(o, static_cast<hipStream_t>(stream));
 }
 
 int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps, const float* d_x,
@@ -928,7 +976,8 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
   Layout o;
   carve(cfg, static_cast<float*>(d_workspace), &o);
   const int M = int(o.M);
-  DDP_TRY(prepare_static(cfg, weights, o, st));
+  DDP_TRY(prepare_model(cfg, weights, o, st));
+  DDP_TRY(prepare_geometry(o, st));
   const float* film = nullptr;
   if (d_temb) {
     for (int l = 0; l < o.L; ++l) {
@@ -1004,6 +1053,62 @@ int ddp_msda_forward(const float* d_value, const float* d_samp, float* d_out, in
     return DDP_E_BADCFG;
   }
   return launch_msda_gather(d_value, d_samp, d_out, rows, h * w, h, w, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+struct MsdaLdsLayout {
+  float *vpad, *samp_hm, *tab_y, *tab_x;
+  unsigned short* out_sb;
+  size_t vpad_floats, bytes;
+};
+int msda_lds_layout(int rows, int h, int w, char* base, MsdaLdsLayout* o) {
+  if (rows < 1 || h < 1 || w < 1 || rows % (h * w)) {
+    set_error("msda_lds: rows=%d must be a positive multiple of h*w=%d", rows, h * w);
+    return DDP_E_BADCFG;
+  }
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) / 256 * 256;
+    return p;
+  };
+  const size_t R = size_t(rows) / (size_t(h) * w);
+  o->vpad_floats = (R * (h + 2) + 1) * (w + 2) * 256 + 256;      // + one zero row below the last map, as in the sampler's workspace
+  o->vpad = reinterpret_cast<float*>(take(o->vpad_floats * 4));
+  o->samp_hm = reinterpret_cast<float*>(take(size_t(rows) * DDP_SAMP_STRIDE * 4));
+  o->tab_y = reinterpret_cast<float*>(take(size_t(h) * 96 * 4));
+  o->tab_x = reinterpret_cast<float*>(take(size_t(w) * 96 * 4));
+  o->out_sb = reinterpret_cast<unsigned short*>(take((size_t(rows) + 255) / 256 * 256 * 256 * 6));
+  o->bytes = off;
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_msda_forward_lds_workspace(int rows, int h, int w, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
+  }
+  MsdaLdsLayout o;
+  DDP_TRY(msda_lds_layout(rows, h, w, nullptr, &o));
+  *bytes = o.bytes;
+  return DDP_OK;
+}
+
+int ddp_msda_forward_lds(const float* d_value, const float* d_samp, const float* d_guess, float* d_out, int rows, int h, int w,
+                         void* d_workspace, void* stream) {
+  DDP_TRY(check_ptr(d_value, "value"));
+  DDP_TRY(check_ptr(d_samp, "samp"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  MsdaLdsLayout o;
+  DDP_TRY(msda_lds_layout(rows, h, w, static_cast<char*>(d_workspace), &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DDP_TRY(launch_msda_lds_adapters_in(d_value, d_samp, d_guess, o.vpad, o.vpad_floats, o.samp_hm, o.tab_y, o.tab_x, rows, h * w, h, w,
+                                      st));
+  // the kernel of the sampling loop, launched exactly as encoder_forward launches it
+  DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp_hm, o.out_sb, rows, h * w, h, w, o.tab_y, o.tab_x, d_guess ? 0 : 1, st));
+  return launch_sb_to_row(o.out_sb, d_out, rows, 256, st);
 }
 
 int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k, int gelu,
@@ -1154,6 +1259,31 @@ int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h
   a.flip = flip;
   a.seg = d_seg;
   return launch_seg_postprocess(a, static_cast<hipStream_t>(stream));
+}
+
+int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int num_classes, int out_h, int out_w,
+                            int align_corners, unsigned char* d_seg, float* d_prob, void* stream) {
+  if (!augs || !d_seg) {
+    set_error("seg_aug_postprocess: augs / seg is NULL");
+    return DDP_E_NULL;
+  }
+  if (n_aug < 1 || n_aug > DDP_MAX_AUGS || batch < 1 || num_classes < 1 || num_classes > 256 || out_h < 1 || out_w < 1) {
+    set_error("seg_aug_postprocess: bad arguments (n_aug %d B %d K %d out %dx%d)", n_aug, batch, num_classes, out_h, out_w);
+    return DDP_E_BADCFG;
+  }
+  for (int i = 0; i < n_aug; ++i) {
+    const ddp_seg_aug& g = augs[i];
+    DDP_TRY(check_ptr(g.d_scores, "aug scores"));
+    if (g.h < 1 || g.w < 1 || g.img_h < 1 || g.img_w < 1 || g.crop_h < 1 || g.crop_w < 1 || g.crop_h > g.img_h ||
+        g.crop_w > g.img_w || g.flip < 0 || g.flip > 2) {
+      set_error("seg_aug_postprocess: augmentation %d: bad geometry (map %dx%d image %dx%d crop %dx%d flip %d)", i, g.h, g.w,
+                g.img_h, g.img_w, g.crop_h, g.crop_w, g.flip);
+      return DDP_E_BADCFG;
+    }
+  }
+  if (d_prob) DDP_TRY(check_ptr(d_prob, "prob"));
+  return launch_seg_aug_postprocess(augs, n_aug, batch, num_classes, out_h, out_w, align_corners ? 1 : 0, d_seg, d_prob,
+                                    static_cast<hipStream_t>(stream));
 }
 
 namespace {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/ddp_mi355x.h"
 
 // The sample table the layer kernel's P3 epilogue hands to the LDS-staged gather is head-major: [head][token][8 pixel
@@ -13,27 +14,34 @@ namespace ddp {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// Per-(kernel, device) one-time setup.  A process may drive several GPUs (one engine per device): the dynamic-LDS
-// attribute has to be set on each of them, and the CU count is a property of the device the launch goes to - neither
-// may be cached process-wide.  The bit mask is idempotent state (a race only repeats the call).
+// Per-(kernel, device) one-time setup.  A process may drive several GPUs (one engine per device, possibly from several host
+// threads): the dynamic-LDS attribute has to be set on each of them, and the CU count is a property of the device the
+// launch goes to - neither may be cached process-wide.  Atomics: concurrent launches can at worst repeat the (idempotent) call.
 struct LdsAttrOnce {
-  unsigned long long done = 0;                       // bit per device id < 64
+  std::atomic<unsigned long long> done{0};           // bit per device id < 64
   void ensure(const void* fn, int bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      (void)hipGetLastError();                       // the launch that follows fails and reports through check_launch
+      set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d", bytes, dev);
+      return;
+    }
+    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
   }
 };
 inline int cu_count() {                              // compute units of the CURRENT device (persistent-kernel grids)
-  static int cache[64] = {0};
+  static std::atomic<int> cache[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  if (dev >= 0 && dev < 64) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
   int n = 0;
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  if (dev >= 0 && dev < 64) cache[dev] = n;
+  if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
   return n;
 }
 
@@ -182,6 +190,10 @@ int launch_msda_gather_sb(const float* value, const float* samp, unsigned short*
                           hipStream_t st);
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                               const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st);
+// adapters of ddp_msda_forward_lds: plain layouts -> padded map / head-major table / guess tables, SB -> row-major
+int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,
+                                float* samp_hm, float* tab_y, float* tab_x, int rows, int n_tok, int h, int w, hipStream_t st);
+int launch_sb_to_row(const unsigned short* in_sb, float* out, int rows, int C, hipStream_t st);
 int launch_sinusoid(const float* freq, const float* time_in_dev, int S, float* u, hipStream_t st);
 // y[s][o] = out_act( W[o][:] . in_act(x[s][:]) + b[o] )   act: 0 none, 1 gelu(out), 2 silu(in)
 int launch_matvec(const float* W, const float* b, const float* x, float* y, int in_dim, int out_dim, int S,
@@ -220,6 +232,8 @@ struct SegPostArgs {
   unsigned char* seg;       // (B,oh,ow)
 };
 int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
+int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K, int oh, int ow, int align, unsigned char* seg,
+                               float* prob, hipStream_t st);
 struct MsmArgs {
   const float* level[4];    // token-major (B, N_l, 256)
   int lh[4], lw[4];

@@ -644,6 +644,68 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Adapters that put the PRODUCT gather (k_msda_gather_lds) behind the plain interface of ddp_msda_forward (row-major value
+// map, token-major sample table, row-major output): ddp_msda_forward_lds.  In the loop these conversions do not exist -
+// the layer kernel's P3 writes the padded map and the head-major table, the next layer kernel's P0 reads SB.
+// ------------------------------------------------------------------------------------------------
+// value (R, h*w, 256) row-major -> interior of the zero-padded maps (R, h+2, w+2, 256); one wave per token
+__global__ void __launch_bounds__(256) k_pad_value(const float* __restrict__ value, float* __restrict__ vpad, int rows, int n_tok,
+                                                    int w, int h) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int img = m / n_tok, t = m - img * n_tok;
+  const int i = t / w, j = t - i * w;
+  const size_t row = size_t(img) * (h + 2) * (w + 2) + size_t(i + 1) * (w + 2) + (j + 1);
+  *reinterpret_cast<f32x4*>(vpad + row * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(value + size_t(m) * 256 + lane * 4);
+}
+// token-major table rows of DDP_SAMP_STRIDE floats [64 coords (head, point, xy) | 32 weights (head, point)] -> head-major
+// [head][token][8 coords | 4 weights]
+__global__ void __launch_bounds__(256) k_samp_head_major(const float* __restrict__ samp, float* __restrict__ out, int rows) {
+  const long idx = long(blockIdx.x) * 256 + threadIdx.x;        // (token, head)
+  if (idx >= long(rows) * 8) return;
+  const int m = int(idx >> 3), hd = int(idx & 7);
+  const float* sp = samp + size_t(m) * DDP_SAMP_STRIDE;
+  float* dst = out + (size_t(hd) * rows + m) * 12;
+  *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp + hd * 8);
+  *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + hd * 8 + 4);
+  *reinterpret_cast<f32x4*>(dst + 8) = *reinterpret_cast<const f32x4*>(sp + 64 + hd * 4);
+}
+// SB (rows padded to 32, C channels) -> fp32 row-major: the three bf16 pieces of an element sum to its fp32 value exactly
+__global__ void __launch_bounds__(256) k_sb_to_row(const unsigned short* __restrict__ in_sb, float* __restrict__ out, int rows, int C) {
+  const int slots = C / 8;
+  const long idx = long(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= long(rows) * slots) return;
+  const int m = int(idx / slots), sl = int(idx - long(m) * slots);
+  const int b = sl >> 1, h = sl & 1;
+  const char* base = reinterpret_cast<const char*>(in_sb) + size_t(m >> 5) * C * 192 + size_t(b) * 3 * 1024 + (h * 32 + (m & 31)) * 16;
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = 0.f;
+#pragma unroll
+  for (int c = 2; c >= 0; --c) {                       // smallest piece first: every partial sum is exact
+    const uint4 q = *reinterpret_cast<const uint4*>(base + c * 1024);
+    const unsigned d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] += __uint_as_float((u & 1) ? (d[u >> 1] & 0xFFFF0000u) : (d[u >> 1] << 16));
+  }
+  float* dst = out + size_t(m) * C + 16 * b + 4 * h;
+  *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(dst + 8) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// separable guess tables of the LDS gather for a per-head constant guess (gx, gy): tab_y[i][hd*8 + 2p (+1)] = g (the kernel
+// averages the four points of tab_y + tab_x), tab_x = 0
+__global__ void k_fill_guess_tables(const float* __restrict__ guess /* (8,2) or nullptr */, float* __restrict__ tab_y,
+                                    float* __restrict__ tab_x, int h, int w) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < h * 96) {
+    const int c = idx % 96;
+    tab_y[idx] = (guess && c < 64) ? guess[(c >> 3) * 2 + (c & 1)] : 0.f;
+  }
+  if (idx < w * 96) tab_x[idx] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Post-loop epilogue of the segmentor, fused: bilinear resize of the low-resolution class
 // scores to the (padded) image size (segmentors/ddp.py:124-128), crop to img_shape + bilinear resize to ori_shape
 // (encoder_decoder.py:236-248), softmax (:277, monotone: skipped), flip (:278-285), argmax (:296) -> uint8 map.
@@ -795,6 +857,83 @@ __global__ void __launch_bounds__(256) k_seg_postprocess_x4(SegPostArgs a) {
       *reinterpret_cast<unsigned*>(a.seg + (size_t(b) * a.oh + oy) * a.ow + 4 * j) = packed;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Test-time-augmentation epilogue (encoder_decoder.py:306-331 aug_test), fused.  One wave = 64 output pixels; per pixel and
+// augmentation: the two-stage bilinear resize of k_seg_postprocess for every class (values parked in LDS), softmax over the
+// classes, accumulation into the pixel's running sum (LDS), flip undone by reading the mirrored source pixel; after the last
+// augmentation: / n_aug, argmax (first maximum wins), optional store of the mean probabilities.
+// LDS: 2 x K x 64 floats (tmp | acc), column = thread -> conflict-free.
+// ------------------------------------------------------------------------------------------------
+struct SegAugArgs {
+  ddp_seg_aug aug[DDP_MAX_AUGS];
+  int n_aug, B, K, oh, ow, align;
+  unsigned char* seg;
+  float* prob;      // optional (B,K,oh,ow)
+};
+__global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
+  extern __shared__ float aug_lds[];
+  float* tmp = aug_lds;
+  float* acc = aug_lds + size_t(a.K) * 64;
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x * 64 + tid;
+  const int y = blockIdx.y;
+  const int b = blockIdx.z;
+  const bool live = x < a.ow;
+  const int xs = live ? x : a.ow - 1;
+  for (int i = 0; i < a.n_aug; ++i) {
+    const ddp_seg_aug& g = a.aug[i];
+    const int sx = g.flip == 1 ? a.ow - 1 - xs : xs;
+    const int sy = g.flip == 2 ? a.oh - 1 - y : y;
+    const bool two_stage = !(a.oh == g.crop_h && a.ow == g.crop_w);
+    const UpIdx Y = up_index(sy, g.crop_h, a.oh, a.align);
+    const UpIdx X = up_index(sx, g.crop_w, a.ow, a.align);
+    const UpIdx ya = up_index(Y.i0, g.h, g.img_h, a.align), yb = up_index(Y.i1, g.h, g.img_h, a.align);
+    const UpIdx xa = up_index(X.i0, g.w, g.img_w, a.align), xb = up_index(X.i1, g.w, g.img_w, a.align);
+    const size_t ps = size_t(g.h) * g.w;
+    const float* plane = g.d_scores + size_t(b) * a.K * ps;
+    float mx = -INFINITY;
+    for (int c = 0; c < a.K; ++c, plane += ps) {
+      const float* r0 = plane + size_t(ya.i0) * g.w;
+      const float* r1 = plane + size_t(ya.i1) * g.w;
+      float v = bilerp(r0[xa.i0], r0[xa.i1], r1[xa.i0], r1[xa.i1], ya, xa);
+      if (two_stage) {
+        const float* q0 = plane + size_t(yb.i0) * g.w;
+        const float* q1 = plane + size_t(yb.i1) * g.w;
+        const float v01 = bilerp(r0[xb.i0], r0[xb.i1], r1[xb.i0], r1[xb.i1], ya, xb);
+        const float v10 = bilerp(q0[xa.i0], q0[xa.i1], q1[xa.i0], q1[xa.i1], yb, xa);
+        const float v11 = bilerp(q0[xb.i0], q0[xb.i1], q1[xb.i0], q1[xb.i1], yb, xb);
+        v = bilerp(v, v01, v10, v11, Y, X);
+      }
+      tmp[c * 64 + tid] = v;
+      mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < a.K; ++c) {
+      const float e = expf(tmp[c * 64 + tid] - mx);
+      tmp[c * 64 + tid] = e;
+      sum += e;
+    }
+    for (int c = 0; c < a.K; ++c) {
+      const float p = tmp[c * 64 + tid] / sum;
+      acc[c * 64 + tid] = i == 0 ? p : acc[c * 64 + tid] + p;
+    }
+  }
+  if (!live) return;
+  const float nf = float(a.n_aug);
+  float best = -INFINITY;
+  int arg = 0;
+  float* pout = a.prob ? a.prob + (size_t(b) * a.K * a.oh + y) * a.ow + x : nullptr;
+  for (int c = 0; c < a.K; ++c) {
+    const float p = acc[c * 64 + tid] / nf;
+    if (pout) pout[size_t(c) * a.oh * a.ow] = p;
+    if (p > best) {
+      best = p;
+      arg = c;
+    }
+  }
+  a.seg[(size_t(b) * a.oh + y) * a.ow + x] = (unsigned char)arg;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1445,6 +1584,24 @@ int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_seg_postprocess, dim3(cdiv(a.ow, 64), cdiv(a.oh, 4), a.B), dim3(256), 0, st, a);
   return check_launch("k_seg_postprocess");
 }
+int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K, int oh, int ow, int align, unsigned char* seg,
+                               float* prob, hipStream_t st) {
+  SegAugArgs a;
+  for (int i = 0; i < n_aug; ++i) a.aug[i] = augs[i];
+  a.n_aug = n_aug;
+  a.B = B;
+  a.K = K;
+  a.oh = oh;
+  a.ow = ow;
+  a.align = align;
+  a.seg = seg;
+  a.prob = prob;
+  const int lds = 2 * K * 64 * int(sizeof(float));
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), lds);
+  hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
+  return check_launch("k_seg_aug_postprocess");
+}
 int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_msm_resize_sb, dim3(cdiv(a.rows, 32)), dim3(64 * GSB_WAVES), 0, st, a);
   return check_launch("k_msm_resize_sb");
@@ -1467,6 +1624,21 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
                      n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");
+}
+int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,
+                                float* samp_hm, float* tab_y, float* tab_x, int rows, int n_tok, int h, int w, hipStream_t st) {
+  if (hipMemsetAsync(vpad, 0, vpad_floats * sizeof(float), st) != hipSuccess) {
+    set_error("hipMemsetAsync(vpad) failed");
+    return DDP_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(k_pad_value, dim3(cdiv(rows, 4)), dim3(256), 0, st, value, vpad, rows, n_tok, w, h);
+  hipLaunchKernelGGL(k_samp_head_major, dim3(cdiv(long(rows) * 8, 256)), dim3(256), 0, st, samp, samp_hm, rows);
+  hipLaunchKernelGGL(k_fill_guess_tables, dim3(cdiv(long(h > w ? h : w) * 96, 256)), dim3(256), 0, st, guess, tab_y, tab_x, h, w);
+  return check_launch("msda_lds adapters (in)");
+}
+int launch_sb_to_row(const unsigned short* in_sb, float* out, int rows, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_sb_to_row, dim3(cdiv(long(rows) * (C / 8), 256)), dim3(256), 0, st, in_sb, out, rows, C);
+  return check_launch("k_sb_to_row");
 }
 int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
                            int B, int N, float eps, hipStream_t st) {

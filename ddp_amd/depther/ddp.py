@@ -84,7 +84,9 @@ class DDP(nn.Module, _SamplerMixin):
             return DDPEngine(self.hot_path_state_dict(), 'depth', h=h, w=w, batch=b, randsteps=self.randsteps,
                              timesteps=self.timesteps, bit_scale=self.bit_scale, time_difference=self.time_difference,
                              min_depth=self.min_depth, max_depth=self.max_depth, device=x.device)
-        eng = self._get_engine((b, h, w, str(x.device), self.timesteps, self.randsteps, self.bit_scale), factory)
+        # keyed without the geometry: a new (b, h, w) re-uses the engine through set_geometry (no weight repacking)
+        eng = self._get_engine(('depth', str(x.device), self.timesteps, self.randsteps, self.bit_scale, self.time_difference,
+                                self.min_depth, self.max_depth), factory, geometry=(b, h, w))
         return eng.sample(x.contiguous().float(), noise.contiguous().float())
 
     def _decode_head_forward_test(self, x, t, img_metas=None):

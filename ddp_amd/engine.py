@@ -164,13 +164,49 @@ class DDPEngine:
             for k, v in r.items():
                 setattr(self.steps[i], k, v)
         nbytes = C.c_size_t(0)
-        _lib.check(self.lib.ddp_query_workspace(C.byref(cfg), C.byref(nbytes)))
+        _lib.check(self.lib.ddp_query_workspace(C.byref(cfg), C.byref(nbytes)), self.lib)
         self.workspace = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        cbytes = C.c_size_t(0)
+        _lib.check(self.lib.ddp_query_const_workspace(C.byref(cfg), C.byref(cbytes)), self.lib)
+        self._const_floats = cbytes.value // 4       # model region: a prefix of the workspace, independent of the geometry
         self._prepared = False
+        self.geometry_changes = 0
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def geometry(self):
+        return (self.cfg.batch, self.cfg.h, self.cfg.w)
+
+    def set_geometry(self, batch=None, h=None, w=None, grow=1.25):
+        """Switch the engine to another (batch, h, w) WITHOUT touching anything derived from the weights: the reference's
+        test protocol is one image per call with a new size almost every call (segmentation/tools/test.py:214-219).
+        The model region of the workspace (split weight planes, weight streams, LUTs, time / FiLM vectors) is kept - moved
+        with one device-to-device copy if the buffer has to grow - and only ``ddp_prepare_geometry`` runs (positional
+        tables + the zero border of the padded value maps)."""
+        c = self.cfg
+        nb = c.batch if batch is None else int(batch)
+        nh = c.h if h is None else int(h)
+        nw = c.w if w is None else int(w)
+        if (nb, nh, nw) == (c.batch, c.h, c.w):
+            return self
+        c.batch, c.h, c.w = nb, nh, nw
+        if self.task != 'bev':                      # bev: the decoder grid comes from the grid transform's output scope
+            c.head_h, c.head_w = nh, nw
+        nbytes = C.c_size_t(0)
+        _lib.check(self.lib.ddp_query_workspace(C.byref(c), C.byref(nbytes)), self.lib)
+        need = nbytes.value // 4
+        if need > self.workspace.numel():
+            new = torch.empty(int(need * grow), dtype=torch.float32, device=self.device)
+            if self._prepared:
+                new[:self._const_floats].copy_(self.workspace[:self._const_floats])
+            self.workspace = new
+        if self._prepared:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.ddp_prepare_geometry(C.byref(c), self.workspace.data_ptr(), self._stream()), self.lib)
+        self.geometry_changes += 1
+        return self
 
     def out_shape(self):
         c = self.cfg
@@ -277,6 +313,8 @@ class FcnSamplerEngine:
             assert step_noise is not None and step_noise.is_contiguous() and step_noise.numel() == c.timesteps * noise.numel()
         if out is None:
             out = torch.empty((c.batch, c.num_classes, c.h, c.w), dtype=torch.float32, device=self.device)
+        if x.device != self.device or noise.device != self.device or out.device != self.device:
+            raise _lib.DdpError(f'engine lives on {self.device}: x / noise / out must be on the same device')
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ddp_sample_fcn(C.byref(c), C.byref(self.weights.struct), self.convs, self.head.num_convs,
                                                self.head.dilation, self.steps, x.data_ptr(), noise.data_ptr(),
@@ -306,4 +344,59 @@ def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corne
     with torch.cuda.device(scores.device):
         _lib.check(lib.ddp_seg_postprocess(scores.data_ptr(), B, K, h, w, H, W, ch, cw, oh, ow, int(bool(align_corners)), fl,
                                            out.data_ptr(), torch.cuda.current_stream(scores.device).cuda_stream))
+    return out
+
+
+def seg_aug_postprocess(scores_list, metas, out_size, align_corners=False, return_prob=False):
+    """Fused multi-scale / flip epilogue (``ddp_seg_aug_postprocess``): class map (B,out_h,out_w) uint8 from the low-resolution
+    scores of every augmentation.  Replaces, per augmentation, resize -> crop -> resize -> softmax -> flip of the reference's
+    ``inference`` and the running mean + argmax of ``aug_test`` (encoder_decoder.py:229-331) without materialising any
+    (B,K,H,W) tensor.  ``metas[i]`` = dict(img_size=(H,W), crop_size=(h,w) or None, flip=None|'horizontal'|'vertical')."""
+    if not scores_list or len(scores_list) != len(metas) or len(scores_list) > _lib.MAX_AUGS:
+        raise ValueError(f'seg_aug_postprocess: 1..{_lib.MAX_AUGS} augmentations with one meta each')
+    dev = scores_list[0].device
+    if not scores_list[0].is_cuda:
+        raise _lib.DdpError('seg_aug_postprocess: scores must be CUDA tensors (no CPU path)')
+    B, K = scores_list[0].shape[:2]
+    keep = []
+    augs = (_lib.DdpSegAug * len(scores_list))()
+    for i, (sc, m) in enumerate(zip(scores_list, metas)):
+        sc = sc.contiguous().float()
+        if sc.device != dev or sc.shape[0] != B or sc.shape[1] != K:
+            raise ValueError('seg_aug_postprocess: every augmentation needs the same batch / classes / device')
+        keep.append(sc)
+        H, W = int(m['img_size'][0]), int(m['img_size'][1])
+        ch, cw = (H, W) if m.get('crop_size') is None else (int(m['crop_size'][0]), int(m['crop_size'][1]))
+        augs[i].d_scores = sc.data_ptr()
+        augs[i].h, augs[i].w = sc.shape[2], sc.shape[3]
+        augs[i].img_h, augs[i].img_w, augs[i].crop_h, augs[i].crop_w = H, W, ch, cw
+        augs[i].flip = {None: 0, False: 0, 'horizontal': 1, 'vertical': 2}[m.get('flip')]
+    oh, ow = int(out_size[0]), int(out_size[1])
+    seg = torch.empty((B, oh, ow), dtype=torch.uint8, device=dev)
+    prob = torch.empty((B, K, oh, ow), dtype=torch.float32, device=dev) if return_prob else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ddp_seg_aug_postprocess(augs, len(keep), B, K, oh, ow, int(bool(align_corners)), seg.data_ptr(),
+                                               prob.data_ptr() if prob is not None else None,
+                                               torch.cuda.current_stream(dev).cuda_stream), lib)
+    return (seg, prob) if return_prob else seg
+
+
+def msda_forward_lds(value, samp, h, w, guess=None):
+    """The deformable-attention core computed by the kernel the sampling loop runs (``ddp_msda_forward_lds``):
+    value (R, h*w, 256), samp (R*h*w, 96) as for ``ddp_msda_forward``; guess (8,2) optional per-head window guess."""
+    if not value.is_cuda:
+        raise _lib.DdpError('msda_forward_lds: CUDA tensors only (no CPU path)')
+    value, samp = value.contiguous().float(), samp.contiguous().float()
+    rows = samp.shape[0]
+    lib = _lib.load()
+    nbytes = C.c_size_t(0)
+    _lib.check(lib.ddp_msda_forward_lds_workspace(rows, h, w, C.byref(nbytes)), lib)
+    ws = torch.empty(nbytes.value // 4 + 64, dtype=torch.float32, device=value.device)
+    out = torch.empty((rows, 256), dtype=torch.float32, device=value.device)
+    g = guess.contiguous().float() if guess is not None else None
+    with torch.cuda.device(value.device):
+        _lib.check(lib.ddp_msda_forward_lds(value.data_ptr(), samp.data_ptr(), g.data_ptr() if g is not None else None,
+                                            out.data_ptr(), rows, h, w, ws.data_ptr(),
+                                            torch.cuda.current_stream(value.device).cuda_stream), lib)
     return out

@@ -42,19 +42,42 @@ def _build_neck(neck):
 
 
 class _SamplerMixin:
-    """engine cache shared by the task variants."""
+    """engine cache shared by the task variants.
+
+    One ``PackedWeights`` blob per (device, weights version) and a small LRU of engines keyed by everything EXCEPT the
+    geometry: a new (batch, h, w) - the normal case under the reference's test protocol, one keep-ratio-resized image per
+    call (segmentation/tools/test.py:214-219, mmseg/apis/test.py:87-89) - re-uses the engine through ``set_geometry`` (positional
+    tables + workspace carve only; no weight repacking, no ``ddp_prepare``)."""
+    ENGINE_CACHE_SIZE = 4
 
     def _weights_version(self):
         return sum(p._version for p in self.parameters())
 
-    def _get_engine(self, key, factory):
+    def _packed_weights(self, device, task, num_layers):
+        from ..engine import PackedWeights
+        ver = self._weights_version()
+        cache = self.__dict__.setdefault('_weights_cache', {})
+        key = (str(device), task, num_layers)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, PackedWeights(self.hot_path_state_dict(), task, num_layers, device))
+            cache[key] = hit
+        return hit[1]
+
+    def _get_engine(self, key, factory, geometry=None):
         cache = self.__dict__.setdefault('_engine_cache', {})
-        key = key + (self._weights_version(),)
-        eng = cache.get(key)
+        ver = self._weights_version()
+        for k in [k for k in cache if k[-1] != ver]:      # weights changed: every cached engine is stale
+            del cache[k]
+        key = key + (ver,)
+        eng = cache.pop(key, None)
         if eng is None:
-            cache.clear()
             eng = factory()
-            cache[key] = eng
+            while len(cache) >= self.ENGINE_CACHE_SIZE:
+                cache.pop(next(iter(cache)))               # least recently used
+        elif geometry is not None:
+            eng.set_geometry(*geometry)
+        cache[key] = eng                                   # most recently used last
         return eng
 
 
@@ -110,25 +133,29 @@ class DDP(nn.Module, _SamplerMixin):
             times.append(t[:, None].repeat(1, batch))
         return times
 
-    def _engine_for(self, b, h, w, device, sampler):
+    def _engine_for(self, b, h, w, device, sampler, timesteps=None, randsteps=None, accumulation=None, kind='sample'):
+        from ..decode_heads.fcn_head_with_time import FCNHeadWithTime
+        K = self.timesteps if timesteps is None else timesteps
+        r = self.randsteps if randsteps is None else randsteps
+        acc = self.accumulation if accumulation is None else accumulation
+        common = dict(batch=b, randsteps=r, timesteps=K, num_classes=self.num_classes, bit_scale=self.bit_scale,
+                      time_difference=self.time_difference, sample_range0=self.sample_range[0],
+                      noise_schedule=self.noise_schedule, sampler=sampler, accumulation=acc, device=device)
+        key = (kind, str(device), sampler, K, r, acc, self.bit_scale, self.time_difference, self.sample_range[0],
+               self.noise_schedule)
+        if isinstance(self.decode_head, FCNHeadWithTime):
+            # any registered head goes through _decode_head_forward_test in the reference (ddp.py:192-196); here the loop
+            # around FCNHeadWithTime is its own C entry (ddp_sample_fcn), one engine per geometry
+            def factory():
+                from ..engine import FcnSamplerEngine
+                return FcnSamplerEngine(self.hot_path_state_dict(), self.decode_head, h=h, w=w, **common)
+            return self._get_engine(key + ('fcn', b, h, w), factory)
+
         def factory():
-            from ..engine import DDPEngine, FcnSamplerEngine
-            from ..decode_heads.fcn_head_with_time import FCNHeadWithTime
-            if isinstance(self.decode_head, FCNHeadWithTime):
-                # any registered head goes through _decode_head_forward_test in the reference (ddp.py:192-196); here the
-                # loop around FCNHeadWithTime is its own C entry (ddp_sample_fcn)
-                return FcnSamplerEngine(self.hot_path_state_dict(), self.decode_head, h=h, w=w, batch=b,
-                                        randsteps=self.randsteps, timesteps=self.timesteps, num_classes=self.num_classes,
-                                        bit_scale=self.bit_scale, time_difference=self.time_difference,
-                                        sample_range0=self.sample_range[0], noise_schedule=self.noise_schedule,
-                                        sampler=sampler, accumulation=self.accumulation, device=device)
-            return DDPEngine(self.hot_path_state_dict(), 'seg', h=h, w=w, batch=b, randsteps=self.randsteps,
-                             timesteps=self.timesteps, num_classes=self.num_classes, feat_channels=256,
-                             bit_scale=self.bit_scale, time_difference=self.time_difference,
-                             sample_range0=self.sample_range[0], noise_schedule=self.noise_schedule,
-                             sampler=sampler, accumulation=self.accumulation, device=device)
-        return self._get_engine((b, h, w, str(device), sampler, self.timesteps, self.randsteps, self.accumulation,
-                                 self.bit_scale), factory)
+            from ..engine import DDPEngine, count_layers
+            nl = count_layers(self.hot_path_state_dict())
+            return DDPEngine(None, 'seg', h=h, w=w, feat_channels=256, weights=self._packed_weights(device, 'seg', nl), **common)
+        return self._get_engine(key, factory, geometry=(b, h, w))
 
     def hot_path_state_dict(self):
         return {k: v for k, v in self.state_dict().items()
@@ -206,13 +233,29 @@ class DDP(nn.Module, _SamplerMixin):
 
     def aug_test(self, imgs, img_metas, rescale=True):
         """encoder_decoder.py:306-331: mean of the per-augmentation probabilities (multi-scale / flip), then argmax.
-        Every augmentation runs the full sampling loop with its own noise, as in the reference."""
+        Every augmentation runs the full sampling loop with its own noise, as in the reference; only the LOW-RESOLUTION
+        scores of each are kept, and one fused epilogue (``ddp_seg_aug_postprocess``) does resize -> crop -> resize ->
+        softmax -> flip-undo for all of them, the mean and the argmax per output pixel: the (1,K,H,W) tensors ``inference``
+        materialises per augmentation and the running sum at ori_shape never exist."""
+        from ..engine import seg_aug_postprocess
         assert rescale, 'aug_test rescales every augmentation back to ori_shape'
-        seg_logit = self.inference(imgs[0], img_metas[0], rescale)
-        for i in range(1, len(imgs)):
-            seg_logit += self.inference(imgs[i], img_metas[i], rescale)
-        seg_logit /= len(imgs)
-        return list(seg_logit.argmax(dim=1).cpu().numpy())
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        ori_shape = tuple(img_metas[0][0]['ori_shape'][:2])
+        scores, metas = [], []
+        for img, meta in zip(imgs, img_metas):
+            assert all(tuple(m['ori_shape'][:2]) == ori_shape for m in meta)
+            x = self.extract_feat(img)[0]
+            if self.diffusion == 'ddim':
+                scores.append(self.ddim_sample(x, meta))
+            elif self.diffusion == 'ddpm':
+                scores.append(self.ddpm_sample(x, meta))
+            else:
+                raise NotImplementedError
+            metas.append(dict(img_size=tuple(img.shape[2:]), crop_size=tuple(meta[0]['img_shape'][:2]),
+                              flip=meta[0].get('flip_direction', 'horizontal') if meta[0].get('flip', False) else None))
+        seg = seg_aug_postprocess(scores, metas, ori_shape, self.align_corners)
+        return list(seg.cpu().numpy().astype('int64'))
 
     @staticmethod
     def _epilogue_args(meta, rescale):
@@ -295,12 +338,8 @@ class SelfAlignedDDP(DDP):
         if noise is None:
             noise = torch.randn_like(x)
 
-        def factory():
-            from ..engine import DDPEngine
-            return DDPEngine(self.hot_path_state_dict(), 'seg', h=h, w=w, batch=b, randsteps=1, timesteps=1,
-                             num_classes=self.num_classes, feat_channels=256, bit_scale=self.bit_scale,
-                             noise_schedule=self.noise_schedule, sampler='ddim', accumulation=False, device=x.device)
-        eng = self._get_engine(('self_aligned', b, h, w, str(x.device), self.bit_scale, self.noise_schedule), factory)
+        # the head dispatch of _engine_for (the reference's pre-pass goes through the generic _decode_head_forward_test)
+        eng = self._engine_for(b, h, w, x.device, 'ddim', timesteps=1, randsteps=1, accumulation=False, kind='self_aligned')
         logits = eng.sample(x.contiguous().float(), noise.reshape(b, 1, c, h, w).contiguous().float())
         preds = torch.empty((b, 256, h, w), dtype=torch.float32, device=x.device)
         emb = self.embedding_table.weight.detach().float().contiguous()

@@ -20,7 +20,8 @@
  *  - return value: DDP_OK (0) or a negative DDP_E_* code; `ddp_last_error()` gives a message.
  *    No exception crosses the boundary.
  *  - thread-safety: re-entrant per (workspace, stream); no global mutable state except the
- *    thread-local last-error string.
+ *    thread-local last-error string and the measurement hook at the end of this header
+ *    (ddp_profile_*: ONE process-wide session, armed by bench.py only - not thread-safe, see there).
  *  - fixed architecture constants of the reference configs: embed 256, 8 heads x 32, 4 points,
  *    1 level, FFN 1024, time dim 1024, 16 learned sinusoid features.
  */
@@ -38,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define DDP_ABI_VERSION 3
+#define DDP_ABI_VERSION 4
 #define DDP_MAX_LAYERS 12
 #define DDP_MAX_STEPS 64
 #define DDP_EMBED 256
@@ -139,6 +140,19 @@ int ddp_query_workspace(const ddp_cfg* cfg, size_t* bytes);
 int ddp_prepare(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* steps,
                 void* d_workspace, void* stream);
 
+/* Serving the reference's own test protocol - ONE image per call, a different (h, w) almost every call
+ * (segmentation/tools/test.py:214-219 forces samples_per_gpu = 1; configs/_base_/datasets/ade20k.py:23 resizes keep-ratio):
+ * the workspace starts with a MODEL region (everything ddp_prepare derives from the weights and the schedule: time
+ * embeddings, FiLM, folded affines, x0 LUT and T = LUT.W_m^T, split weight planes, the layer kernels' weight streams) whose
+ * size and content do not depend on batch / randsteps / (h, w) / (head_h, head_w) / the bev grid.  When only those change:
+ *   - keep a buffer of at least ddp_query_workspace(new cfg) bytes whose first ddp_query_const_workspace(cfg) bytes are the
+ *     prepared model region (same buffer, or a device-to-device copy of that prefix into a larger one),
+ *   - call ddp_prepare_geometry(new cfg, ...) : L positional-table launches + one memset, no weight is touched.
+ * Every other cfg field (task, sampler, timesteps, num_layers, num_classes, feat_channels, gemm_mode, flags, bit_scale, ...)
+ * must be unchanged since ddp_prepare. */
+int ddp_query_const_workspace(const ddp_cfg* cfg, size_t* bytes);
+int ddp_prepare_geometry(const ddp_cfg* cfg, void* d_workspace, void* stream);
+
 /* The whole K-step loop for B images: replaces DDP.ddim_sample / ddpm_sample / sample.
  *   d_x          (B, Cx, h, w)           frozen neck feature, NCHW
  *   d_noise      (B, r, Cm, h, w)        start noise (the reference draws torch.randn in-method)
@@ -168,6 +182,17 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
  *   [head][point][x,y] followed by 32 softmaxed weights [head][point]; d_out (R*N, 256). */
 int ddp_msda_forward(const float* d_value, const float* d_samp, float* d_out, int rows, int h, int w,
                      void* stream);
+
+/* The same core computed by the kernel the SAMPLING LOOP runs (k_msda_gather_lds: one head per block, the head's 128-B
+ * slices of a window of the zero-padded value map staged in LDS, taps outside the window served from global memory), behind
+ * the same plain interface: the entry pads the map, transposes the table to head-major, launches the loop's gather exactly
+ * as ddp_sample does and converts its split-bf16 output back to fp32 rows (exact).  d_guess: (8,2) per-head (x, y) guess of
+ * the mean sampling offset that positions the LDS window before the table is read (the loop derives it from the offset bias
+ * and the positional tables), or NULL = zero guess; results do not depend on it (it only decides which taps hit LDS).
+ * This is the entry the adversarial tests use: on-pixel, far-outside, NaN and border-straddling sample points. */
+int ddp_msda_forward_lds_workspace(int rows, int h, int w, size_t* bytes);
+int ddp_msda_forward_lds(const float* d_value, const float* d_samp, const float* d_guess, float* d_out, int rows, int h, int w,
+                         void* d_workspace, void* stream);
 
 /* out[M][N] = A[M][K] * W[N][K]^T + bias  (fp32 MFMA), optional exact GELU. K % 32 == 0. */
 int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k,
@@ -206,6 +231,24 @@ int ddp_seg_x0_project(const float* d_scores, int batch, int num_classes, int n_
 int ddp_seg_postprocess(const float* d_scores, int batch, int num_classes, int h, int w, int img_h, int img_w,
                         int crop_h, int crop_w, int out_h, int out_w, int align_corners, int flip,
                         unsigned char* d_seg, void* stream);
+
+/* Multi-scale / flip test-time augmentation epilogue, fused (encoder_decoder.py:306-331 `aug_test` over :251-287 `inference`
+ * over :229-248 `whole_inference` over segmentors/ddp.py:124-128): for every augmentation a
+ *   resize of its low-resolution scores to its network input -> crop to img_shape -> resize to ori_shape -> softmax ->
+ *   flip undone,
+ * then the mean over the augmentations and argmax.  One thread per output pixel walks all augmentations: neither the per-
+ * augmentation (B,K,H,W) tensors nor the (B,K,ori_h,ori_w) running sum of the reference are materialised.
+ * d_seg (B,out_h,out_w) uint8; d_prob optional (B,K,out_h,out_w) mean probabilities (tests / callers that need them). */
+#define DDP_MAX_AUGS 16
+typedef struct ddp_seg_aug {
+  const float* d_scores;   /* (B,K,h,w): ddp_sample's output for this augmentation */
+  int32_t h, w;            /* its map size */
+  int32_t img_h, img_w;    /* its (padded) network input */
+  int32_t crop_h, crop_w;  /* its img_shape */
+  int32_t flip;            /* 0 none, 1 horizontal, 2 vertical: undone on the probabilities */
+} ddp_seg_aug;
+int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int num_classes, int out_h, int out_w,
+                            int align_corners, unsigned char* d_seg, float* d_prob, void* stream);
 
 /* MultiStageMerging neck (necks/multi_stage_merging.py:40-52): the step that produces the frozen
  * feature x of the sampling loop from the four FPN levels: bilinear resize of every level to level 0's grid, concat
@@ -264,11 +307,13 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
                    const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
                    void* d_workspace, void* stream);
 
-/* Measurement hook (bench.py roofline leg; not part of the reference surface): arm HIP-event timing
+/* Measurement hook (bench.py roofline leg; not part of the reference surface, NOT thread-safe: one process-wide session;
+ * two threads sampling with a session armed would interleave their records): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
  * tag: 1 xproj, 2 feat / step prologue, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN / the
  * layer kernel, 8 head conv / seg tail, 9 deformable gather; 255 = all of them at once.  ddp_profile_end synchronises on
- * the recorded events and returns the sum over all records; ddp_profile_read then gives one call site's share. */
+ * the recorded events and returns the sum over all records; ddp_profile_read then gives one call site's share
+ * (DDP_E_BADCFG for an unknown tag or when no finished session exists). */
 int ddp_profile_begin(int tag);
 int ddp_profile_end(float* total_ms, int* launches);
 int ddp_profile_read(int tag, float* total_ms, int* launches);

@@ -260,13 +260,15 @@ def x0_from_logits_seg(logits, sd, bit_scale, idx=None):
 
 def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time_difference=1,
                     sample_range0=0.0, noise_schedule='cosine', accumulation=False,
-                    core='gridsample', trace=None, head=None, x0_index=None):
+                    core='gridsample', trace=None, head=None, x0_index=None, decisions=None):
     """SEGDDP:215-246 for ONE image.  x (1,256,h,w); noise (r,256,h,w) replaces the in-method
     ``torch.randn`` (SEGDDP:220).  -> (1,K,h,w).  ``head(feat, temb) -> logits`` replaces the decode head that
     ``_decode_head_forward_test`` (SEGDDP:192-196) dispatches to (default: DeformableHeadWithTime).
     ``x0_index``: optional K maps (r,h,w) of class indices used INSTEAD of argmax(logits) in the x0 projection - the
     loop's only discrete decision.  Feeding the decisions another implementation took removes the feedback
-    discontinuity from a comparison (everything else is continuous in the inputs)."""
+    discontinuity from a comparison (everything else is continuous in the inputs).
+    ``decisions``: optional list that receives the class map (r,h,w) uint8 every step fed back (a light-weight
+    alternative to ``trace`` at full size)."""
     log_snr_fn = alpha_cosine_log_snr if noise_schedule == 'cosine' else beta_linear_log_snr
     xr = x.repeat(randsteps, 1, 1, 1)
     mask_t = noise.clone()
@@ -285,6 +287,8 @@ def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
         layer_trace = [] if trace is not None else None
         logits = head(feat, temb) if head is not None else head_forward_seg(feat, temb, sd, core, layer_trace)
         x0 = x0_from_logits_seg(logits, sd, bit_scale, None if x0_index is None else x0_index[step].long())
+        if decisions is not None:
+            decisions.append((torch.argmax(logits, dim=1) if x0_index is None else x0_index[step]).to(torch.uint8))
         pred_noise = (mask_t - alpha * x0) / sigma.clamp(min=1e-8)
         mask_t = x0 * alpha_next + pred_noise * sigma_next
         if accumulation:
@@ -294,6 +298,42 @@ def ddim_sample_seg(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.01, time
     if accumulation:
         logits = torch.cat(outs, dim=0)
     return logits.mean(dim=0, keepdim=True)
+
+
+def reference_drift_seg(x, noise, sd, *, timesteps, accumulation, bit_scale=0.01, randsteps=1, variants=('taps', 'fp64'),
+                        base=None, base_decisions=None):
+    """How far does the REFERENCE, restated twice, drift from itself when the sampler runs freely (each run taking its
+    own argmax, SEGDDP:235)?  Base = this oracle as pinned (fp32, ``F.grid_sample`` core = the reference's CPU path,
+    MSDA:94-151); variants differ from it only in ways the reference itself does between deployments:
+      'taps'  the deformable-attention core as explicit 4-corner bilinear taps in pixel units - the arithmetic of mmcv's
+              compiled ``ms_deform_attn_forward`` (MSDA:47-53), i.e. the reference's own GPU path, still fp32;
+      'fp64'  every tensor and weight in double precision (the schedule scalars stay the reference's fp32 values).
+    The loop is continuous in its inputs except for the argmax fed back each step, so any two fp32-class evaluations
+    agree to rounding until a near-tie pixel falls the other way; from then on that neighbourhood differs by O(1e-3).
+    Returns {'base': scores, 'ref_vs_ref': worst max-rel over the variants, 'variants': {name: {max_rel,
+    pixels_above_1e-4, decisions_differ}}} - the yardstick the engine's free-running distance is judged against
+    (tests/test_full_size_parity.py, bench.py)."""
+    if base is None:
+        base_decisions = []
+        base = ddim_sample_seg(x, noise, sd, timesteps=timesteps, randsteps=randsteps, bit_scale=bit_scale,
+                               accumulation=accumulation, decisions=base_decisions)
+    res = {}
+    for v in variants:
+        dec = []
+        if v == 'taps':
+            o = ddim_sample_seg(x, noise, sd, timesteps=timesteps, randsteps=randsteps, bit_scale=bit_scale,
+                                accumulation=accumulation, core='taps', decisions=dec)
+        elif v == 'fp64':
+            o = ddim_sample_seg(x.double(), noise.double(), {k: t.double() for k, t in sd.items()}, timesteps=timesteps,
+                                randsteps=randsteps, bit_scale=bit_scale, accumulation=accumulation, decisions=dec)
+        else:
+            raise ValueError(v)
+        rel = (o.to(base.dtype) - base).abs().amax(1) / base.abs().max()
+        res[v] = {'max_rel': float(rel.max()), 'pixels_above_1e-4': int((rel > 1e-4).sum()),
+                  'decisions_differ': (sum(int((a != b).sum()) for a, b in zip(dec, base_decisions))
+                                       if base_decisions is not None else None)}
+    return {'base': base, 'base_decisions': base_decisions, 'ref_vs_ref': max(r['max_rel'] for r in res.values()) if res else 0.0,
+            'variants': res}
 
 
 def ddpm_sample_seg(x, noise, step_noise, sd, timesteps=3, randsteps=1, bit_scale=0.01,
@@ -454,6 +494,27 @@ def seg_postprocess(scores, img_size, crop_size=None, out_size=None, align_corne
     elif flip == 'vertical':
         o = o.flip(dims=(2,))
     return o.argmax(dim=1)
+
+
+def seg_aug_test(scores_list, metas, out_size, align_corners=False):
+    """Multi-scale / flip test-time augmentation, the reference's own op sequence: per augmentation ``inference``
+    (encoder_decoder.py:251-287) = softmax of ``whole_inference`` (:229-248: resize to the network input [segmentors/
+    ddp.py:124-128], crop to img_shape, resize to ori_shape) with the flip undone; then ``aug_test`` (:306-331): running sum,
+    / n, argmax.  scores_list[i] (B,K,h_i,w_i); metas[i] = dict(img_size, crop_size, flip) -> (int64 (B,oh,ow), mean prob)."""
+    acc = None
+    for sc, m in zip(scores_list, metas):
+        o = F.interpolate(sc, size=tuple(m['img_size']), mode='bilinear', align_corners=align_corners)
+        crop = m.get('crop_size') or m['img_size']
+        o = o[:, :, :crop[0], :crop[1]]
+        o = F.interpolate(o, size=tuple(out_size), mode='bilinear', align_corners=align_corners)
+        o = F.softmax(o, dim=1)
+        if m.get('flip') == 'horizontal':
+            o = o.flip(dims=(3,))
+        elif m.get('flip') == 'vertical':
+            o = o.flip(dims=(2,))
+        acc = o if acc is None else acc + o
+    acc = acc / len(scores_list)
+    return acc.argmax(dim=1), acc
 
 
 def neck_multi_stage_merging(levels, sd, align_corners=False, prefix=''):

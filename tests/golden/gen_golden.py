@@ -318,6 +318,63 @@ def gen_post():
              dict(seg=seg.astype('uint8'), margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=fingerprint(scores)))
 
 
+AUG_CASES = [
+    # multi-scale x horizontal flip on a Cityscapes-like head: 3 scales x {plain, flipped}; img_shape < padded input
+    dict(name='aug_ms3_hflip', num_classes=19, ori_shape=(40, 50), align_corners=False, seed=0,
+         augs=[dict(h=8, w=10, img=(32, 40), img_shape=(30, 38), flip=None), dict(h=8, w=10, img=(32, 40), img_shape=(30, 38), flip='horizontal'),
+               dict(h=10, w=13, img=(40, 52), img_shape=(40, 50), flip=None), dict(h=10, w=13, img=(40, 52), img_shape=(40, 50), flip='horizontal'),
+               dict(h=15, w=19, img=(60, 76), img_shape=(60, 75), flip=None), dict(h=15, w=19, img=(60, 76), img_shape=(60, 75), flip='horizontal')]),
+    # ADE-like: 150 classes, flip only, no second resize for the plain augmentation (img_shape == ori_shape == input)
+    dict(name='aug_ade_flip', num_classes=150, ori_shape=(48, 64), align_corners=False, seed=1,
+         augs=[dict(h=12, w=16, img=(48, 64), img_shape=(48, 64), flip=None), dict(h=12, w=16, img=(48, 64), img_shape=(48, 64), flip='horizontal')]),
+    # vertical flip + align_corners=True + odd sizes
+    dict(name='aug_vflip_ac', num_classes=19, ori_shape=(37, 45), align_corners=True, seed=2,
+         augs=[dict(h=9, w=11, img=(36, 44), img_shape=(33, 41), flip=None), dict(h=9, w=11, img=(36, 44), img_shape=(33, 41), flip='vertical'),
+               dict(h=13, w=17, img=(52, 68), img_shape=(50, 66), flip='vertical')]),
+]
+
+
+def gen_aug():
+    """Multi-scale / flip test-time augmentation (encoder_decoder.py:306-331) through the reference's own aug_test /
+    inference / whole_inference / encode_decode; backbone and sampler replaced by seeded per-augmentation scores."""
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in AUG_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.test_cfg.mode = 'whole'
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        model.align_corners = case['align_corners']
+        scores = [synthetic.make_scores(1, case['num_classes'], a['h'], a['w'], case['seed'] * 100 + i) for i, a in enumerate(case['augs'])]
+        calls = []
+        model.extract_feat = lambda img: [None]
+
+        def sample(x, img_metas, _calls=calls, _scores=scores):
+            _calls.append(1)
+            return _scores[(len(_calls) - 1) % len(_scores)].clone()
+        model.ddim_sample = sample
+        imgs = [torch.zeros((1, 3) + tuple(a['img'])) for a in case['augs']]
+        metas = [[dict(img_shape=tuple(a['img_shape']) + (3,), ori_shape=tuple(case['ori_shape']) + (3,),
+                       pad_shape=tuple(a['img']) + (3,), flip=a['flip'] is not None,
+                       flip_direction=a['flip'] or 'horizontal')] for a in case['augs']]
+        seg = model.aug_test(imgs, metas, rescale=True)[0]
+        # the mean probabilities the argmax was taken of (same calls again: the stub cycles through the scores)
+        prob = model.inference(imgs[0], metas[0], True)
+        for i in range(1, len(imgs)):
+            prob += model.inference(imgs[i], metas[i], True)
+        prob /= len(imgs)
+        assert (prob.argmax(1)[0].numpy() == seg).all()
+        top2 = prob.topk(2, dim=1).values
+        save(case['name'], dict(task='aug', **case),
+             dict(seg=seg.astype('uint8'), prob=prob[0], margin=(top2[:, 0] - top2[:, 1])[0],
+                  scores_fp=np.stack([fingerprint(t) for t in scores])))
+
+
 NECK_CASES = [
     dict(name='neck_msm_even', batch=2, h=16, w=24, align_corners=False, seed=0),
     dict(name='neck_msm_odd', batch=1, h=13, w=19, align_corners=False, seed=1),
@@ -507,16 +564,16 @@ def gen_loopfcn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
         {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn,
-         'aligned': gen_aligned, 'loopfcn': gen_loopfcn}[args.task]()
+         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug}[args.task]()
 
 
 if __name__ == '__main__':

@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -60,6 +60,16 @@ def load_post_case(name):
     scores = synthetic.make_scores(1, cfg['num_classes'], cfg['h'], cfg['w'], cfg['seed'])
     assert np.allclose(fingerprint(scores), z['scores_fp'], rtol=1e-12)
     return cfg, scores, torch.from_numpy(z['seg']), torch.from_numpy(z['margin'])
+
+
+def load_aug_case(name):
+    """Test-time-augmentation fixture (reference ``aug_test``): -> (cfg, [scores_i (1,K,h_i,w_i)], metas, seg uint8, prob, margin)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    scores = [synthetic.make_scores(1, cfg['num_classes'], a['h'], a['w'], cfg['seed'] * 100 + i) for i, a in enumerate(cfg['augs'])]
+    assert np.allclose(np.array([fingerprint(t) for t in scores]), z['scores_fp'], rtol=1e-12)
+    metas = [dict(img_size=tuple(a['img']), crop_size=tuple(a['img_shape']), flip=a['flip']) for a in cfg['augs']]
+    return cfg, scores, metas, torch.from_numpy(z['seg']), torch.from_numpy(z['prob']), torch.from_numpy(z['margin'])
 
 
 def load_neck_case(name):

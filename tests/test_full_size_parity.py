@@ -88,9 +88,11 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
       (2) the engine's decision at every step and pixel must be a maximiser of the ORACLE's scores up to rounding: the
           oracle's top score minus its score of the engine's class <= 1e-4 of the score scale - asserted, and the
           number of pixels where the two argmaxes differ is printed.
-    (1) + (2) = "identical to the reference up to which of two equal-to-rounding classes wins a tie".  The free-running
-    comparison (oracle taking its own decisions) is printed beside it; it is bounded loosely (1e-2) because one flipped
-    near-tie moves its neighbourhood by up to ~bit_scale-sized changes of the noisy map (SURVEY.md §7 hard part 1)."""
+    (1) + (2) = "identical to the reference up to which of two equal-to-rounding classes wins a tie".
+      (3) ``free_running`` (a tuple of oracle variants): the comparison with the oracle taking its own decisions, judged
+          against how far the REFERENCE RESTATED TWICE drifts from itself on the same image (one flipped near-tie moves its
+          neighbourhood by up to ~bit_scale-sized changes of the noisy map, SURVEY.md §7 hard part 1): asserted
+          free-running <= max(1e-3, 2 x reference-vs-reference); the three figures are printed on one line."""
     from oracle import ddp_oracle as O
     tr = eng.x0_trace()[:, b:b + 1].cpu().long()                             # (K, 1, h, w)
     trace = []
@@ -110,9 +112,20 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
           f'largest oracle score gap at such a pixel {worst_gap:.3e} (score scale {scale:.2f})')
     assert worst_gap <= 1e-4 * scale
     if free_running:
-        ref_free = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.01, accumulation=accumulation)
-        err_f, agree_f = _report(f'{name} image {b} (free-running oracle)', out[b:b + 1], ref_free)
-        assert err_f <= 1e-2 and agree_f >= 0.9995
+        # (3) free-running: the oracle takes its OWN argmax every step.  The yardstick is the reference restated twice
+        # (oracle.reference_drift_seg: grid_sample core vs explicit-tap core = its CPU vs its compiled-GPU arithmetic, and
+        # fp32 vs fp64): how far two evaluations of the REFERENCE drift apart on this very image once a near-tie falls the
+        # other way.  Asserted: the engine's free-running distance is within the north_star gate or within 2x that drift.
+        variants = free_running if isinstance(free_running, (tuple, list)) else ('taps', 'fp64')
+        dr = O.reference_drift_seg(x[b:b + 1], noise[b], sd, timesteps=K, accumulation=accumulation, bit_scale=0.01, variants=variants)
+        err_f, agree_f = _report(f'{name} image {b} (free-running oracle)', out[b:b + 1], dr['base'])
+        flips_free = sum(int((a != t).sum()) for a, t in zip(dr['base_decisions'], [tr[s].to(torch.uint8) for s in range(K)]))
+        print(f'{name} image {b}: THREE FIGURES  decisions-fed {err:.3e} | free-running {err_f:.3e} ({flips_free} decisions differ) | '
+              f'reference-vs-reference {dr["ref_vs_ref"]:.3e} ' +
+              ', '.join(f'[{v}: {d["max_rel"]:.3e}, {d["pixels_above_1e-4"]} px above 1e-4, {d["decisions_differ"]} decisions differ]'
+                        for v, d in dr['variants'].items()))
+        assert err_f <= max(GATE, 2 * dr['ref_vs_ref']) and agree_f >= 0.9995
+    return err
 
 
 def test_c2_ade_8x512x1024_k3(dev):
@@ -138,7 +151,7 @@ def test_c2_ade_8x512x1024_k3(dev):
                      accumulation=True, device=dev, gather_guess_zero=True)
     assert torch.equal(engz.sample(x.to(dev), noise.to(dev)).cpu(), out)
     del engz
-    for b, free in ((0, True), (5, True)):
+    for b, free in ((0, ('taps', 'fp64')), (5, ('fp64',))):
         _seg_parity_with_decisions('C2', eng, out, x, noise, sd, b, K, True, free)
     eng1 = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=1, num_classes=ncls, bit_scale=0.01,
                      accumulation=False, device=dev)
@@ -162,9 +175,12 @@ def test_c3_cityscapes_4x1024x2048_k10(dev):
                     accumulation=False, device=dev, record_x0=True)
     out = eng.sample(x.to(dev), noise.to(dev)).cpu()
     assert torch.isfinite(out).all()
-    # ten steps of argmax feedback on 131 072 pixels: the free-running comparison measured 1.5e-3 / 208 pixels above 1e-4
-    # (r02b) - two flipped near-ties; with the decisions fed to the oracle the same call is at rounding level
-    _seg_parity_with_decisions('C3', eng, out, x, noise, sd, 2, K, False, False)
+    # ten steps of argmax feedback on 131 072 pixels.  Decisions fed: rounding level.  Free-running: a handful of flipped
+    # near-ties put the engine ~1.5e-3 from the oracle (r02b) - and put the reference's own two deformable-attention cores
+    # (grid_sample, its CPU path, vs explicit taps, the arithmetic of its compiled GPU kernel; both fp32) 0.97e-3 apart on
+    # this image (119 pixels above 1e-4, 4 decisions differ; measured in the build container, 8 cores).  The fp64 variant
+    # is left out here for time (it costs another 2.5 oracle-minutes; build container: 1.5e-5, 12 decisions differ)
+    _seg_parity_with_decisions('C3', eng, out, x, noise, sd, 2, K, False, ('taps',))
     del eng
     from oracle import ddp_oracle as O
     eng1 = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=1, num_classes=ncls, bit_scale=0.01,
@@ -272,6 +288,36 @@ def test_c2_size_trained_like_weights(dev):
     print(f'C2-size, trained-like weights, K = {K} (probabilities, decisions fed): gpu vs fp64 oracle max {dg:.3e}; '
           f'fp32 oracle vs fp64 oracle max {dc:.3e}; final argmax agreement with fp64: gpu {agree:.6f}, fp32 oracle {agree_c:.6f}')
     assert dg <= 4 * dc + 1e-5 and agree >= agree_c - 2e-3
+
+
+def test_c3_size_trained_like_weights(dev):
+    """The trained-like weight profile (see test_c2_size_trained_like_weights) at the Cityscapes map size: one image of
+    256 x 512 tokens, 19 classes, 3 steps of argmax feedback (the spatial size is what this adds: 4x the tiles, windows of
+    a 512-wide map; the 10-step accumulation of rounding is test_c3's subject).  Same fp32-class bar against fp64."""
+    from ddp_amd.engine import DDPEngine
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    h, w, K, ncls = 256, 512, 3, 19
+    sd = synthetic.make_state_dict('seg', ncls, 6, 256, seed=8, profile='trained_like')
+    x, noise = synthetic.make_inputs(1, h, w, 1, 256, 256, seed=6)
+    eng = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=K, num_classes=ncls, bit_scale=0.01,
+                    accumulation=False, device=dev, record_x0=True)
+    out = eng.sample(x.to(dev), noise.to(dev)).cpu()
+    assert torch.isfinite(out).all()
+    tr = eng.x0_trace()[:, :1].cpu().long()
+    idx = [tr[s] for s in range(K)]
+    r32 = O.ddim_sample_seg(x, noise[0], sd, timesteps=K, randsteps=1, bit_scale=0.01, accumulation=False, x0_index=idx)
+    r64 = O.ddim_sample_seg(x.double(), noise[0].double(), _dbl(sd), timesteps=K, randsteps=1, bit_scale=0.01,
+                            accumulation=False, x0_index=idx)
+    sc = float(r64.abs().max())
+    dg = float((out.double() - r64).abs().max())
+    dc = float((r32.double() - r64).abs().max())
+    agree = float((out.argmax(1) == r64.argmax(1)).float().mean())
+    agree_c = float((r32.argmax(1) == r64.argmax(1)).float().mean())
+    print(f'C3-size, trained-like weights, K = {K} (last-step scores, decisions fed): gpu vs fp64 oracle max {dg:.3e}; '
+          f'fp32 oracle vs fp64 oracle max {dc:.3e} (score scale {sc:.2f}); final argmax agreement with fp64: gpu {agree:.6f}, '
+          f'fp32 oracle {agree_c:.6f}')
+    assert dg <= 4 * dc + 1e-5 * sc and agree >= agree_c - 2e-3
 
 
 def test_c1_ade_1x512x512_k1(dev):

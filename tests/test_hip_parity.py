@@ -115,6 +115,84 @@ def test_msda_forward(dev, h, w, r):
     assert max_rel(out.cpu().reshape(r, n, 256), ref) < 1e-5
 
 
+@pytest.mark.parametrize('h,w,r', [(13, 17, 2), (32, 48, 1), (5, 70, 3), (70, 9, 1), (8, 16, 1), (41, 67, 2)])
+@pytest.mark.parametrize('table', ['wild', 'ring'])
+def test_msda_forward_lds(dev, h, w, r, table):
+    """The gather of the SAMPLING LOOP (k_msda_gather_lds: zero-padded map, head-major table, LDS window per (tile, head),
+    mixed LDS / global path) behind the plain msda interface (ddp_msda_forward_lds), on adversarial sample tables:
+      'wild'  N(0, 3 px) offsets, every 7th token exactly on pixel centres, every 11th 20x further out (far outside the
+              map: clamped, zero contribution), so nearly every 8-token group leaves its window (mixed path);
+      'ring'  the reference's initialisation - a per-head ring of radius 1..4 px (multi_scale_deform_attn.py:233-244) - plus
+              0.3 px of content-dependent noise: windows hold, the staged path serves the taps; maps smaller than the
+              8 x 16 tile in either direction, windows straddling every border.
+    Against the oracle's explicit-tap restatement (vendored mmcv multi_scale_deform_attn.py:94-151); the window guess
+    (none / per-head mean / deliberately wrong) must not change a single bit."""
+    import math
+    from ddp_amd.engine import msda_forward_lds
+    from oracle import ddp_oracle as O
+    n = h * w
+    g = torch.Generator().manual_seed(h * 100 + w + (7 if table == 'ring' else 0))
+    value = torch.randn(r, n, 8, 32, generator=g)
+    if table == 'wild':
+        off = torch.randn(r, n, 8, 4, 2, generator=g) * 3.0
+        off[:, ::7] = torch.round(off[:, ::7])
+        off[:, 3::11] *= 20.0
+    else:
+        th = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+        grid = torch.stack([th.cos(), th.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True).values                       # (8,2) unit ring, max-normalised
+        ring = grid[:, None, :] * (torch.arange(4, dtype=torch.float32) + 1)[None, :, None]      # radius 1..4 per point
+        off = ring[None, None] + 0.3 * torch.randn(r, n, 8, 4, 2, generator=g)
+    aw = torch.randn(r, n, 8, 4, generator=g).softmax(-1)
+    jj = torch.arange(w, dtype=torch.float32).repeat(h)
+    ii = torch.arange(h, dtype=torch.float32).repeat_interleave(w)
+    px = jj[None, :, None, None] + off[..., 0]
+    py = ii[None, :, None, None] + off[..., 1]
+    ref = O.msda_core_taps(value, h, w, px, py, aw)
+    samp = torch.cat([torch.stack((px, py), -1).reshape(r * n, 64), aw.reshape(r * n, 32)], 1).contiguous()
+    dv, ds = value.reshape(r, n, 256).to(dev), samp.to(dev)
+    out = msda_forward_lds(dv, ds, h, w)
+    assert max_rel(out.cpu().reshape(r, n, 256), ref) < 1e-5
+    mean_guess = off.mean(dim=(0, 1, 3)).to(dev)                                    # (8,2): what the loop derives from bias + pos tables
+    assert torch.equal(msda_forward_lds(dv, ds, h, w, guess=mean_guess), out)
+    assert torch.equal(msda_forward_lds(dv, ds, h, w, guess=mean_guess + 5.0), out)  # wrong guess -> refill branch
+    # the wave-per-token kernel of the unfused path computes the same values
+    from ddp_amd import _lib
+    lib = _lib.load()
+    out2 = torch.empty(r * n, 256, device=dev)
+    _lib.check(lib.ddp_msda_forward(dv.data_ptr(), ds.data_ptr(), out2.data_ptr(), r * n, h, w, torch.cuda.current_stream().cuda_stream))
+    assert max_rel(out2.cpu(), out.cpu()) < 1e-5
+
+
+def test_msda_forward_lds_nan_and_inf_coordinates(dev):
+    """NaN / +-inf sample coordinates (they only arise from NaN inputs): the product gather does not fault, the affected
+    (token, head) outputs stay finite (the point is clamped to the zero border), every other output is unchanged."""
+    from ddp_amd.engine import msda_forward_lds
+    h, w, r = 19, 37, 1
+    n = h * w
+    g = torch.Generator().manual_seed(5)
+    value = torch.randn(r, n, 256, generator=g)
+    off = torch.randn(r, n, 8, 4, 2, generator=g)
+    aw = torch.randn(r, n, 8, 4, generator=g).softmax(-1)
+    jj = torch.arange(w, dtype=torch.float32).repeat(h)
+    ii = torch.arange(h, dtype=torch.float32).repeat_interleave(w)
+    xy = torch.stack((jj[None, :, None, None] + off[..., 0], ii[None, :, None, None] + off[..., 1]), -1)
+    clean = torch.cat([xy.reshape(n, 64), aw.reshape(n, 32)], 1).contiguous()
+    bad_xy = xy.clone()
+    bad_xy[0, 5::13, 2, 1, 0] = float('nan')
+    bad_xy[0, 6::17, 4, 3, 1] = float('inf')
+    bad_xy[0, 7::19, 6, 0, 0] = float('-inf')
+    bad = torch.cat([bad_xy.reshape(n, 64), aw.reshape(n, 32)], 1).contiguous()
+    a = msda_forward_lds(value.to(dev), clean.to(dev), h, w).cpu().reshape(n, 8, 32)
+    b = msda_forward_lds(value.to(dev), bad.to(dev), h, w).cpu().reshape(n, 8, 32)
+    assert torch.isfinite(b).all()
+    touched = torch.zeros(n, 8, dtype=torch.bool)
+    touched[5::13, 2] = True
+    touched[6::17, 4] = True
+    touched[7::19, 6] = True
+    assert torch.equal(a[~touched], b[~touched])
+
+
 def test_time_embed(dev):
     """LearnedSinusoidalPosEmb + time_mlp + per-layer FiLM on device vs oracle, at the ill-conditioned
     log-SNR values of the real schedule."""
@@ -225,6 +303,57 @@ def test_post_epilogue_golden(name):
     diff = got != seg
     assert diff.float().mean() < 1e-3
     assert not (diff & (margin > 1e-5)).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('aug'))
+def test_aug_epilogue_golden(name):
+    """fused multi-scale / flip epilogue (ddp_seg_aug_postprocess) vs the reference's own aug_test: mean probabilities to
+    rounding, class map identical wherever the reference's top-2 margin is above interpolation / exp rounding noise."""
+    from golden_util import load_aug_case
+    from ddp_amd.engine import seg_aug_postprocess
+    cfg, scores, metas, seg, prob, margin = load_aug_case(name)
+    got, p = seg_aug_postprocess([t.cuda() for t in scores], metas, cfg['ori_shape'], cfg['align_corners'], return_prob=True)
+    torch.cuda.synchronize()
+    assert max_rel(p[0].cpu(), prob) < 2e-6
+    diff = got[0].cpu() != seg
+    assert diff.float().mean() < 1e-3
+    assert not (diff & (margin > 1e-5)).any()
+    # without the probability output: the same class map
+    assert torch.equal(seg_aug_postprocess([t.cuda() for t in scores], metas, cfg['ori_shape'], cfg['align_corners']), got)
+
+
+@pytest.mark.gpu
+def test_aug_epilogue_full_size_and_errors():
+    """ADE-size multi-scale + flip (6 augmentations of a 512x683 image, 150 classes): equals the oracle's aug_test on the
+    class map up to near-ties; one augmentation without flip / rescale == the plain epilogue kernel; bad arguments raise."""
+    from ddp_amd.engine import seg_aug_postprocess, seg_postprocess
+    from ddp_amd import _lib
+    from ddp_amd.utils import synthetic
+    ori = (512, 683)
+    augs = []
+    for i, s in enumerate((0.5, 1.0, 1.5)):
+        H, W = int(ori[0] * s + 0.5), int(ori[1] * s + 0.5)
+        Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+        for flip in (None, 'horizontal'):
+            augs.append((synthetic.make_scores(1, 150, Hp // 4, Wp // 4, 70 + i), dict(img_size=(Hp, Wp), crop_size=(H, W), flip=flip)))
+    scores, metas = [a[0] for a in augs], [a[1] for a in augs]
+    seg, p = seg_aug_postprocess([t.cuda() for t in scores], metas, ori, False, return_prob=True)
+    ref, rp = O.seg_aug_test(scores, metas, ori, False)
+    assert max_rel(p.cpu(), rp) < 2e-6
+    top2 = rp.topk(2, dim=1).values
+    diff = seg.cpu().long() != ref
+    assert diff.float().mean() < 1e-3 and not (diff & ((top2[:, 0] - top2[:, 1]) > 1e-5)).any()
+    assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-5)
+    one = seg_aug_postprocess([scores[2].cuda()], [dict(img_size=metas[2]['img_size'], crop_size=metas[2]['crop_size'], flip=None)], ori)
+    plain = seg_postprocess(scores[2].cuda(), metas[2]['img_size'], metas[2]['crop_size'], ori)
+    assert (one != plain).float().mean() < 1e-4          # softmax is monotone: only exp-rounding ties may differ
+    with pytest.raises(_lib.DdpError):
+        seg_aug_postprocess([torch.zeros(1, 19, 4, 4)], [dict(img_size=(16, 16))], (16, 16))          # CPU tensor
+    with pytest.raises(_lib.DdpError):
+        seg_aug_postprocess([torch.zeros(1, 19, 4, 4).cuda()], [dict(img_size=(16, 16), crop_size=(32, 16))], (16, 16))
+    with pytest.raises(ValueError):
+        seg_aug_postprocess([torch.zeros(1, 19, 4, 4).cuda()] * 17, [dict(img_size=(16, 16))] * 17, (16, 16))
 
 
 @pytest.mark.gpu

@@ -228,9 +228,9 @@ def test_neck_chain_resolves_from_the_reference_config_dict():
 
 
 def test_inference_and_aug_test_post_processing():
-    """``inference`` / ``aug_test`` (encoder_decoder.py:251-331) around a stand-in ``encode_decode``: crop to img_shape,
-    resize to ori_shape, softmax, flip undone, mean over the augmentations, argmax - the host logic only (the loop
-    itself has no CPU path)."""
+    """``inference`` (encoder_decoder.py:251-287) around a stand-in ``encode_decode``: crop to img_shape, resize to
+    ori_shape, softmax, flip undone - the host logic only; ``aug_test`` (:306-331) is a fused HIP epilogue and, like the
+    loop itself, has no CPU path."""
     import torch.nn.functional as F
     model = ddp_amd.build_segmentor(seg_cfg(test_cfg=dict(mode='whole'))).eval()
     K, H, W = model.num_classes, 16, 24
@@ -253,11 +253,15 @@ def test_inference_and_aug_test_post_processing():
     assert torch.allclose(model.inference(img, [plain], True), expect(base, False))
     assert torch.allclose(model.inference(img_f, [flipped], True), expect(base.flip(dims=(3,)), True))
     assert model.inference(img, None, False).shape == (1, K, H, W)
-    got = model.aug_test([img, img_f], [[plain], [flipped]])
-    want = ((expect(base, False) + expect(base.flip(dims=(3,)), True)) / 2).argmax(1)[0].numpy()
-    assert len(got) == 1 and (got[0] == want).all()
-    # forward() dispatch: one augmentation -> simple_test (needs the GPU), several -> aug_test
-    assert (model([img, img_f], [[plain], [flipped]], return_loss=False)[0] == want).all()
+    # aug_test runs the sampling loop per augmentation and ONE fused epilogue kernel over their low-resolution scores
+    # (ddp_seg_aug_postprocess; GPU tests: test_aug_epilogue_golden against the reference's own aug_test,
+    # test_segmentor_aug_test_matches_inference_mean): like the loop it has no CPU path
+    model.extract_feat = lambda im: [torch.zeros(1, 256, H // 4, W // 4)]
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model.aug_test([img, img_f], [[plain], [flipped]])
+    # forward() dispatch: one augmentation -> simple_test, several -> aug_test (both need the GPU)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model([img, img_f], [[plain], [flipped]], return_loss=False)
     with pytest.raises(ValueError):
         model([img, img_f], [[plain]], return_loss=False)
     model.test_cfg = dict(mode='slide', crop_size=(8, 8), stride=(4, 4))

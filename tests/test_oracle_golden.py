@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import ddp_oracle as O
+from golden_util import load_aug_case  # noqa: E402
 from golden_util import case_names, load_case, load_fcn_case, load_fpn_case, load_neck_case, load_post_case, max_rel
 
 TOL = 2e-5   # oracle vs reference on the same CPU: fp32 summation-order noise only
@@ -101,6 +102,15 @@ def test_post_epilogue_golden(name):
     got = O.seg_postprocess(scores, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'], cfg['flip'])[0]
     assert got.shape == seg.shape
     assert torch.equal(got.to(torch.uint8), seg)
+
+
+@pytest.mark.parametrize('name', case_names('aug'))
+def test_aug_test_golden(name):
+    """multi-scale / flip aug_test (encoder_decoder.py:306-331), fixture made by the reference's own aug_test."""
+    cfg, scores, metas, seg, prob, margin = load_aug_case(name)
+    got, p = O.seg_aug_test(scores, metas, cfg['ori_shape'], cfg['align_corners'])
+    assert torch.equal(got[0].to(torch.uint8), seg)
+    assert max_rel(p[0], prob) < TOL
 
 
 @pytest.mark.parametrize('name', case_names('neck'))

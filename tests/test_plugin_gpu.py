@@ -176,3 +176,73 @@ def test_segmentor_batched_harness():
     loader = torch.utils.data.DataLoader(DS(), batch_size=2, shuffle=False, collate_fn=collate)
     res = apis.single_gpu_test(model, loader, pre_eval=True)
     assert res == [(0, (H + 5, W + 3)), (1, (H - 7, W + 9)), (2, (H + 5, W + 3)), (3, (H - 7, W + 9))]
+
+
+def test_segmentor_size_stream_b1():
+    """The reference's own test protocol (segmentation/tools/test.py:214-219, mmseg/apis/test.py:87-89): ONE image per call
+    and a different (h, w) almost every call.  Five sizes, alternating, each call checked against the oracle; the engine and
+    the packed weights are built once (a new size only re-derives the positional tables: ``DDPEngine.set_geometry``), and
+    coming back to a size reproduces the earlier bits."""
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    cfg, sd, _, _, _, _ = load_case('seg_ade_k3')
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    sizes = [(16, 24), (13, 31), (32, 20), (7, 9), (24, 43)]
+    first = {}
+    engines = set()
+    for rnd in range(2):
+        for i, (h, w) in enumerate(sizes if rnd == 0 else sizes[::-1]):
+            x, noise = synthetic.make_inputs(1, h, w, cfg['randsteps'], 256, 256, seed=900 + 7 * h + w)
+            out = model.ddim_sample(x.cuda(), noise=noise.cuda()).cpu()
+            engines.add(id(next(reversed(model._engine_cache.values()))))
+            if rnd == 0:
+                ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
+                                        bit_scale=cfg['bit_scale'], accumulation=cfg['accumulation'])
+                assert max_rel(out, ref) < REL, (h, w)
+                first[(h, w)] = out
+            else:
+                assert torch.equal(out, first[(h, w)]), (h, w)
+    assert len(engines) == 1                                   # one engine served all ten calls
+    eng = next(iter(model._engine_cache.values()))
+    assert eng.geometry_changes == 8                           # 4 new sizes going up, 4 coming back (the turn repeats a size)
+    assert len(model._weights_cache) == 1
+    # a batch of 3 at one of the sizes through the same engine == three single-image calls
+    h, w = sizes[1]
+    xs, ns = zip(*[synthetic.make_inputs(1, h, w, cfg['randsteps'], 256, 256, seed=50 + j) for j in range(3)])
+    outb = model.ddim_sample(torch.cat(xs).cuda(), noise=torch.cat(ns).cuda()).cpu()
+    for j in range(3):
+        assert torch.equal(model.ddim_sample(xs[j].cuda(), noise=ns[j].cuda()).cpu(), outb[j:j + 1])
+    # changing a weight invalidates engines and packed weights
+    with torch.no_grad():
+        model.decode_head.conv_seg.bias.add_(1.0)
+    out2 = model.ddim_sample(xs[0].cuda(), noise=ns[0].cuda()).cpu()
+    assert not torch.equal(out2, outb[:1])
+
+
+def test_segmentor_aug_test_matches_inference_mean():
+    """``aug_test`` (fused multi-scale / flip epilogue) against the reference's formulation composed from this class's own
+    ``inference`` (torch ops, encoder_decoder.py:251-287): same noise, class maps equal up to near-ties."""
+    import numpy as np
+    cfg, sd, x, _, _, _ = load_case('seg_ade_k3')
+    model = _seg_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    H, W = cfg['h'] * 4, cfg['w'] * 4
+    model.backbone = FakeBackbone(x.cuda())
+    img = torch.zeros(1, 3, H, W, device='cuda')
+    ori = (H + 9, W - 5, 3)
+    metas = [[dict(img_shape=(H, W, 3), ori_shape=ori, flip=False)],
+             [dict(img_shape=(H - 3, W - 2, 3), ori_shape=ori, flip=True, flip_direction='horizontal')],
+             [dict(img_shape=(H, W - 1, 3), ori_shape=ori, flip=True, flip_direction='vertical')]]
+    torch.manual_seed(11)
+    got = model.aug_test([img] * 3, metas)[0]
+    torch.manual_seed(11)
+    prob = sum(model.inference(img, m, True) for m in metas) / 3
+    ref = prob.argmax(1)[0].cpu().numpy()
+    top2 = prob.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[0].cpu().numpy()
+    diff = got != ref
+    assert got.shape == ori[:2] and diff.mean() < 1e-3 and not (diff & (margin > 1e-5)).any()
+    assert np.array_equal(model([img] * 3, metas, return_loss=False)[0].shape, ori[:2])
