@@ -159,65 +159,91 @@ def swin_t_standin_ms(B, H, W, dev, timed):
 
 class PowerSampler:
     """Package power (W) and shader clock (MHz) of one GPU, sampled by a background thread while the loop runs.
-    Source: the amdgpu hwmon files in sysfs (power1_average / power1_input in microwatts, freq1_input in Hz) - a plain
-    file read, so 20 ms sampling costs nothing; falls back to `rocm-smi --json` (slower, ~0.3 s per sample).  The part runs
-    this loop at its package power cap, so throughput is set by energy per image: the line carries
-    ``joules_per_image`` next to the roofline fraction."""
+    Sources, in order: the amdsmi python binding shipped with ROCm (gpu_metrics: current_socket_power / current_gfxclk, a few
+    ms per sample), `rocm-smi --showpower --showclocks --json` (~0.3 s per sample; what profiles/r02y used).  The amdgpu hwmon
+    files are NOT used: on the pool's boxes power1_input / freq1_input read 296 W / 2401 MHz whatever the load (r03a).
+    The part runs this loop at its package power cap, so throughput is set by energy per image: the line
+    carries ``joules_per_image`` next to the roofline fraction."""
 
     def __init__(self, index=0, period=0.02):
-        import glob
         self.period = period
         self.samples = []
-        self.power_file = self.clk_file = None
         self.cap_w = None
         self.source = None
-        cards = []
-        for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
-            for name in ('power1_average', 'power1_input'):
-                if os.path.exists(os.path.join(hw, name)):
-                    cards.append((hw, name))
-                    break
-        if cards:
-            hw, name = cards[min(index, len(cards) - 1)]
-            self.power_file = os.path.join(hw, name)
-            self.clk_file = os.path.join(hw, 'freq1_input') if os.path.exists(os.path.join(hw, 'freq1_input')) else None
-            try:
-                self.cap_w = int(open(os.path.join(hw, 'power1_cap')).read()) / 1e6
-            except Exception:
-                pass
-            self.source = 'sysfs hwmon ' + self.power_file
-        else:
-            import shutil
-            self.smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
-            if os.path.exists(self.smi):
-                self.source = 'rocm-smi --showpower --showclocks --json'
-                self.period = 0.05
+        self._smi = self._handle = None
         self._stop = False
         self._thread = None
-
-    def _read(self):
-        if self.power_file:
+        self.first_raw = None
+        try:
+            sys.path.insert(0, '/opt/rocm/share/amd_smi')
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._smi, self._handle = amdsmi, hs[min(index, len(hs) - 1)]
+            if self._read_amdsmi() is None:
+                raise RuntimeError('amdsmi gave no power reading')
+            self.source = 'amdsmi gpu_metrics (current_socket_power, current_gfxclk)'
             try:
-                pw = int(open(self.power_file).read()) / 1e6
-                clk = int(open(self.clk_file).read()) / 1e6 if self.clk_file else None
-                return pw, clk
+                cap = amdsmi.amdsmi_get_power_cap_info(self._handle)
+                c = float(cap.get('power_cap', 0))
+                self.cap_w = c / 1e6 if c > 1e5 else c
             except Exception:
-                return None
+                pass
+        except Exception:
+            self._smi = None
+            import shutil
+            self.smi_cli = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+            if os.path.exists(self.smi_cli) and self._read_cli() is not None:
+                self.source = 'rocm-smi --showpower --showclocks --json'
+                self.period = 0.05
+
+    @staticmethod
+    def _num(v):
+        try:
+            f = float(v)
+            return f if 0 < f < 60000 else None          # 65535 / "N/A" = not available
+        except Exception:
+            return None
+
+    def _read_amdsmi(self):
+        try:
+            m = self._smi.amdsmi_get_gpu_metrics_info(self._handle)
+            if self.first_raw is None:
+                self.first_raw = {k: m.get(k) for k in ('current_socket_power', 'average_socket_power', 'current_gfxclk', 'current_gfxclks',
+                                                        'average_gfxclk_frequency') if k in m}
+            pw = self._num(m.get('current_socket_power')) or self._num(m.get('average_socket_power'))
+            clks = m.get('current_gfxclks')
+            ck = None
+            if isinstance(clks, (list, tuple)):
+                vals = [self._num(c) for c in clks]
+                vals = [c for c in vals if c]
+                ck = sum(vals) / len(vals) if vals else None
+            ck = ck or self._num(m.get('current_gfxclk')) or self._num(m.get('average_gfxclk_frequency'))
+            return (pw, ck) if pw is not None else None
+        except Exception:
+            return None
+
+    def _read_cli(self):
         import re
         import subprocess
         try:
-            txt = subprocess.run([self.smi, '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=5).stdout
+            txt = subprocess.run([self.smi_cli, '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=5).stdout
             card = next(iter(json.loads(txt).values()))
+            if self.first_raw is None:
+                self.first_raw = {k: v for k, v in card.items() if 'Power' in k or k.startswith('sclk')}
             pw = clk = None
             for k, v in card.items():
                 if 'Power' in k and '(W)' in k and pw is None:
-                    pw = float(v)
+                    pw = self._num(v)
                 if k.startswith('sclk clock speed'):
                     m = re.search(r'(\d+)', str(v))
                     clk = float(m.group(1)) if m else None
             return (pw, clk) if pw is not None else None
         except Exception:
             return None
+
+    def _read(self):
+        return self._read_amdsmi() if self._smi is not None else self._read_cli()
 
     def _run(self):
         while not self._stop:
@@ -248,7 +274,7 @@ class PowerSampler:
         ck = [x[2] for x in ss if x[2] is not None]
         return {'power_w': round(sum(pw) / len(pw), 1), 'power_w_max': round(max(pw), 1),
                 'sclk_mhz': round(sum(ck) / len(ck), 0) if ck else None, 'sclk_mhz_min': round(min(ck), 0) if ck else None,
-                'samples': len(ss), 'power_cap_w': self.cap_w, 'source': self.source}
+                'samples': len(ss), 'power_cap_w': self.cap_w, 'source': self.source, 'first_raw_reading': self.first_raw}
 
 
 def size_stream(n_sizes, sd, wl, dev):
@@ -328,7 +354,7 @@ def main():
                          'registered DDP segmentor, every call a different ADE20K-like map size (short side 128 tokens, '
                          'keep-ratio long side); reported under "size_stream", never part of value')
     ap.add_argument('--no-power', action='store_true', help='skip the power / clock sampling leg')
-    ap.add_argument('--power-seconds', type=float, default=2.0, help='length of the back-to-back loop the power leg samples')
+    ap.add_argument('--power-seconds', type=float, default=3.0, help='length of the back-to-back loop the power leg samples')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the process-group code path (RCCL init, weight broadcast, barrier, MAX all_reduce) even at world size 1')
     ap.add_argument('--next-rows', action='store_true',

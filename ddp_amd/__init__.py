@@ -6,7 +6,7 @@ plugin surface (registered ``DDP`` / ``DeformableHeadWithTime`` classes with the
 state_dict keys) and passes torch device pointers to it.  There is no CPU / eager fallback.
 """
 from .registry import (MODELS, SEGMENTORS, HEADS, build_segmentor, build_depther, build_head,  # noqa: F401
-                       register_into_mmseg)
+                       register_into_mmseg, register_into_mmdet3d)
 from .segmentors.ddp import DDP, SelfAlignedDDP  # noqa: F401
 from .decode_heads.deformable_head_with_time import DeformableHeadWithTime  # noqa: F401
 from .decode_heads.fcn_head_with_time import FCNHeadWithTime  # noqa: F401
@@ -16,5 +16,5 @@ from .necks import FPN, MultiStageMerging  # noqa: F401
 from .apis import single_gpu_test, multi_gpu_test, collect_results  # noqa: F401
 
 __all__ = ['DDP', 'SelfAlignedDDP', 'DeformableHeadWithTime', 'FCNHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
-           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg',
+           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg', 'register_into_mmdet3d',
            'single_gpu_test', 'multi_gpu_test', 'collect_results']

@@ -536,13 +536,16 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         DDP_TRY(launch_b3_linear_samp(o.q_sb, o.wp_cat[l], o.py[l], o.px[l], o.Nh, o.wh, o.samp, M, st));
       }
       // a row-major GEMM leaves a plain value map; the layer / prologue kernels write it zero-padded
+      // (the LDS gather feeds the layer kernel only: its output is fp32 in the accumulator layout - o.q1 is free on this path)
       if (own_proj) DDP_TRY(launch_msda_gather_sb(o.v, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, st));
-      else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, M, o.Nh, o.hh, o.wh, o.py[l], o.px[l], o.guess_zero, st));
+      else DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp, o.s_sb, DDP_S_F32 ? o.q1 : nullptr, M, o.Nh, o.hh, o.wh, o.py[l], o.px[l],
+                                             o.guess_zero, st));
       const float* a = aff + size_t(l) * 512;
       if (fused) {
         // output_proj + LN0 + FFN + LN1 + FiLM + the next layer's value / sampling projections: one persistent kernel
         LayerLaunch ll;
         ll.S = o.s_sb;
+        ll.Sf = DDP_S_F32 ? o.q1 : nullptr;
         ll.Q = o.q;
         ll.Q_sb = (sb_out && l + 1 == o.L) ? o.q_sb : nullptr;      // a head GEMM after the encoder reads SB
         ll.stream = o.wstream[l];
@@ -1107,8 +1110,14 @@ int ddp_msda_forward_lds(const float* d_value, const float* d_samp, const float*
   DDP_TRY(launch_msda_lds_adapters_in(d_value, d_samp, d_guess, o.vpad, o.vpad_floats, o.samp_hm, o.tab_y, o.tab_x, rows, h * w, h, w,
                                       st));
   // the kernel of the sampling loop, launched exactly as encoder_forward launches it
-  DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp_hm, o.out_sb, rows, h * w, h, w, o.tab_y, o.tab_x, d_guess ? 0 : 1, st));
+#if DDP_S_F32
+  float* out_blk = reinterpret_cast<float*>(o.out_sb);            // (the SB slot is 1.5x the size of the fp32 fragments)
+  DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp_hm, nullptr, out_blk, rows, h * w, h, w, o.tab_y, o.tab_x, d_guess ? 0 : 1, st));
+  return launch_blk_to_row(out_blk, d_out, rows, st);
+#else
+  DDP_TRY(launch_msda_gather_sb_pad(o.vpad, o.samp_hm, o.out_sb, nullptr, rows, h * w, h, w, o.tab_y, o.tab_x, d_guess ? 0 : 1, st));
   return launch_sb_to_row(o.out_sb, d_out, rows, 256, st);
+#endif
 }
 
 int ddp_linear(const float* d_a, const float* d_w, const float* d_bias, float* d_out, int m, int n, int k, int gelu,
@@ -1454,8 +1463,7 @@ int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_i
     DDP_TRY(check_ptr(v.lat_w, "lateral weight"));
     DDP_TRY(check_ptr(v.out_w, "fpn conv weight"));
     const int N = v.h * v.w, M = batch * N, C = v.in_channels;
-    DDP_TRY(launch_nchw_to_tok(d_in[l], o.tok, batch, C, N, st));
-    DDP_TRY(launch_row_to_sb(o.tok, C, o.a_sb, M, C, st));
+    DDP_TRY(launch_nchw_to_sb(d_in[l], o.a_sb, batch, C, N, st));        // NCHW -> split fragments in one pass (no token-major copy)
     DDP_TRY(launch_split_weights(v.lat_w, C, 256, C, o.wsplit, st));
     SplitW w;
     w.p = o.wsplit;

@@ -173,6 +173,13 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   b3::LayerArgs la;
   memset(&la, 0, sizeof(la));
   la.S = a.S;
+  la.Sf = a.Sf;
+#if DDP_S_F32
+  if (!a.Sf) {
+    set_error("b3::k_layer: this build takes the attention output as fp32 fragments (Sf)");
+    return DDP_E_NULL;
+  }
+#endif
   la.Q = a.Q;
   la.Q_sb = a.Q_sb;
   la.stream = a.stream;

@@ -9,6 +9,18 @@
 // coordinates | 4 attention weights] (the gather runs one head per block); the standalone GEMM epilogue / wave-per-token
 // gathers keep token-major rows of DDP_SAMP_STRIDE floats.  Same size, same workspace slot.
 
+// Build-time variants of the layer kernel / gather pair (same-box A/B builds: scripts/variant_build.sh x -DDDP_S_F32=0):
+//   DDP_S_F32          the LDS gather hands the attention output to the layer kernel as fp32 fragments (1 KiB per token) and
+//                      P0 splits it in its filler slots; 0: as SB (1.5 KiB per token, split in the gather)
+//   DDP_LYR_ASM_LOADS  the layer kernel's own global loads are issued by inline asm so that hipcc's s_waitcnt insertion
+//                      cannot put a vmcnt(0) - "wait for the DMA stage just requested" - in front of their first use
+#ifndef DDP_S_F32
+#define DDP_S_F32 1
+#endif
+#ifndef DDP_LYR_ASM_LOADS
+#define DDP_LYR_ASM_LOADS 1
+#endif
+
 namespace ddp {
 
 void set_error(const char* fmt, ...);
@@ -96,7 +108,8 @@ int launch_b3_linear_samp(const unsigned short* A_sb, const SplitW& wcat, const 
 int launch_build_stages(const unsigned short* Wp, size_t comp_stride, int K, int rows_valid, int tall, int n_rowblk, int n_kblk,
                         int base, int a, int b, int c, unsigned char* stream, hipStream_t st);
 struct LayerLaunch {
-  const unsigned short* S;
+  const unsigned short* S;   // attention output as SB, or
+  const float* Sf;           // as fp32 fragment-major (what the LDS gather writes on the product path)
   float* Q;                 // fp32 fragment-major rows of 256 (residual in, layer output out, in place)
   unsigned short* Q_sb;     // optional: the output also as SB (a tile GEMM consumes it)
   const unsigned char* stream;
@@ -188,8 +201,11 @@ int launch_msda_gather(const float* value, const float* samp, float* out, int ro
                        hipStream_t st);
 int launch_msda_gather_sb(const float* value, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
                           hipStream_t st);
-int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
-                              const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st);
+// the LDS-staged gather of the sampling loop; out_f32_blk != nullptr: fp32 fragment-major output (the layer kernel's S operand),
+// else SB
+int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
+                              int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st);
+int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st);
 // adapters of ddp_msda_forward_lds: plain layouts -> padded map / head-major table / guess tables, SB -> row-major
 int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,
                                 float* samp_hm, float* tab_y, float* tab_x, int rows, int n_tok, int h, int w, hipStream_t st);

@@ -392,7 +392,10 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // 256 threads 0.199 against 0.183 - 0.195 for 8x16 on the same box.  r02u: persistent blocks (3 or 6 per CU and head, tile loop,
 // the next tile's table entries fetched under the current tile's taps) 0.213 - 0.217 against 0.197: one short block per
 // (tile, head), scheduled by the hardware as LDS frees up, overlaps better than a block-level software pipeline.
-template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS>
+// F32OUT: the result leaves as fp32 in the accumulator layout of the layer kernel ([32-token group][tile t = head][quad g]
+// [lane = half * 32 + token][4]: this lane's four channels ARE one 16-B slot of it - no split, no quad exchange; 1 KiB per
+// token instead of the 1.5 KiB of SB); the layer kernel's P0 splits it in its own filler slots (layer_bf16x3.h, DDP_S_F32).
+template <int GL_TH, int GL_TW, int GL_HALO, int MINW, int NT = GL_THREADS, bool F32OUT = false>
 __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __restrict__ vpad, const float* __restrict__ samp,
                                                                     unsigned short* __restrict__ out_sb, int n_tok, int h, int w,
                                                                     int tiles_x, int tiles_y, int n_tiles, int m_total,
@@ -603,6 +606,14 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
           }
           accumulate(v00, v01, v10, v11, a00, a01, a10, a11);
         }
+      }
+      if constexpr (F32OUT) {
+        if (tval[g]) {
+          const int m = int(img_tok) + mtok[g];
+          float* dst = reinterpret_cast<float*>(out_sb) + size_t(m >> 5) * 8192 + hd * 1024 + (q >> 1) * 256 + ((q & 1) * 32 + (m & 31)) * 4;
+          *reinterpret_cast<f32x4*>(dst) = acc;
+        }
+        continue;
       }
       // exact 3-way split of this lane's four channels, THEN the quad exchange with lane q ^ 2 (the other half of the
       // 16-B slot): 6 packed dwords travel instead of 4 fp32 + a second split
@@ -1614,16 +1625,32 @@ int launch_group_norm_nchw(const float* y, double* partial, float* stats, const 
   hipLaunchKernelGGL(k_gn_apply_nchw, dim3(cdiv(N, 64), 4, B), dim3(256), 0, st, y, stats, gamma, beta, out, N);
   return check_launch("group_norm_nchw");
 }
-int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, int rows, int n_tok, int h, int w,
-                              const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {
+int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
+                              int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {
   constexpr int TH = 8, TW = 16, NT = GL_THREADS;
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
-  hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
-                     n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
+  if (out_f32_blk)
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT, true>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp,
+                       reinterpret_cast<unsigned short*>(out_f32_blk), n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x,
+                       zero_guess);
+  else
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT, false>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
+                       n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");
+}
+// fragment-major fp32 (accumulator layout, 256 channels) -> row-major: one wave per token
+__global__ void __launch_bounds__(256) k_blk_to_row(const float* __restrict__ in, float* __restrict__ out, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(in + blk_off256(m, lane * 4));
+}
+int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_blk_to_row, dim3(cdiv(rows, 4)), dim3(256), 0, st, in_blk, out, rows);
+  return check_launch("k_blk_to_row");
 }
 int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,
                                 float* samp_hm, float* tab_y, float* tab_x, int rows, int n_tok, int h, int w, hipStream_t st) {

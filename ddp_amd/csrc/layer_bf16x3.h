@@ -62,7 +62,10 @@ constexpr int LYR_ST_OUT = 8, LYR_ST_FFN = 64, LYR_ST_NEXT = 11;   // next: 8 va
 constexpr int LYR_STAGES = LYR_ST_OUT + LYR_ST_FFN + LYR_ST_NEXT;
 
 struct LayerArgs {
-  const unsigned short* S;       // SB attention output (A operand of output_proj)
+  const unsigned short* S;       // SB A operand of P0 (MODE 2: the start noise; MODE 0 without DDP_S_F32: the attention output)
+  const float* Sf;               // MODE 0 (DDP_S_F32): the attention output as fp32 in the accumulator layout (same as Q): 1 KiB per
+                                 // token instead of the 1.5 KiB of SB, written by the gather without a split; P0 splits it in the
+                                 // filler slots of its own MFMAs
   float* Q;                      // layer input (residual) -> layer output, in place (a block touches only its tokens): fp32 in the
                                  // accumulator layout (fragment-major, gemm_f32.h): [32-token group][tile t][quad g][lane][4] - 4 B per
                                  // element instead of the 6 B of SB; whoever needs it as an MFMA operand splits it after the load
@@ -257,6 +260,33 @@ __device__ __forceinline__ void stream_piece(unsigned long long base, unsigned v
       : "memory", "scc");
 }
 
+// The exact 3-way bf16 split of the eight values of one K16 block (split8) as a list of 44 single non-packed instructions
+// (packed fp32 shares the matrix pipe and does not hide behind an MFMA), so that P0 can hand them out to its filler slots:
+// pair i = ops 11 i .. 11 i + 10:  h0 h1 | r0 r1 | m0 m1 | l0 l1 | pack p1[i] p2[i] p3[i].
+struct SplitState {
+  float h[8], r[8], m[8];
+};
+__device__ __forceinline__ void split_op(int op, SplitState& s, const f32x4& a, const f32x4& b, u32x4 (&p)[3]) {
+  const int i = op / 11, o = op - 11 * i, e0 = 2 * i, e1 = 2 * i + 1;
+  auto x = [&](int e) { return e < 4 ? a[e] : b[e - 4]; };
+  switch (o) {
+    case 0: s.h[e0] = __uint_as_float(__float_as_uint(x(e0)) & 0xFFFF0000u); break;
+    case 1: s.h[e1] = __uint_as_float(__float_as_uint(x(e1)) & 0xFFFF0000u); break;
+    case 2: s.r[e0] = x(e0) - s.h[e0]; break;
+    case 3: s.r[e1] = x(e1) - s.h[e1]; break;
+    case 4: s.m[e0] = __uint_as_float(__float_as_uint(s.r[e0]) & 0xFFFF0000u); break;
+    case 5: s.m[e1] = __uint_as_float(__float_as_uint(s.r[e1]) & 0xFFFF0000u); break;
+    case 6: s.r[e0] = s.r[e0] - s.m[e0]; break;
+    case 7: s.r[e1] = s.r[e1] - s.m[e1]; break;
+    case 8: p[0][i] = __builtin_amdgcn_perm(__float_as_uint(s.h[e1]), __float_as_uint(s.h[e0]), 0x07060302); break;
+    case 9: p[1][i] = __builtin_amdgcn_perm(__float_as_uint(s.m[e1]), __float_as_uint(s.m[e0]), 0x07060302); break;
+    default: p[2][i] = __builtin_amdgcn_perm(__float_as_uint(s.r[e1]), __float_as_uint(s.r[e0]), 0x07060302); break;
+  }
+}
+// ops [SPLIT_HAND_LO[k], SPLIT_HAND_LO[k + 1]) of a K16 block go to filler slot k of ONE MFMA block (the hand-over block of a
+// P0 stage): 3 where the slot already carries a ds_read, 4 - 5 elsewhere
+__device__ constexpr int SPLIT_HAND_LO[13] = {0, 3, 6, 10, 14, 17, 20, 24, 29, 33, 38, 41, 44};
+
 // MODE 0: the decoder layer (output_proj + LN0, FFN + LN1 + FiLM, next layer's projections).
 // MODE 1: the tail of a segmentation step on the same machinery: scores = conv_seg(q) as NCH chunks of 64 classes,
 //         then - per token, in registers - argmax, softmax accumulation, x0 = LUT[argmax], DDIM update of the noisy
@@ -337,6 +367,37 @@ k_layer(LayerArgs la) {
         default: stream_piece<3072, 8192>(nb, voff2, mb); break;
       }
     }
+  };
+
+  // The look-ahead stage's 12 DMA pieces, handed to filler slot k of MFMA block b (0..7) of the running stage:
+  //   spread  one piece in every block and a second one in blocks 0..3 - the FFN, whose fillers are full of GELU;
+  //   front   all twelve in blocks 0..3 - every stage of a phase that has vector-memory operations of its own (P0: S and
+  //           residual fragments; P3: value / table stores, positional loads; conv_seg of the tails).  hipcc's s_waitcnt
+  //           insertion does not see the inline-asm DMA: for a load it does see it counts only its own younger operations and
+  //           emits vmcnt(0..3) in front of the first use - in hardware terms "drain every DMA piece issued since".  With the
+  //           pieces spread over the stage that drained the piece requested ~300 cycles earlier: a forced round trip at the end
+  //           of every P0 stage, in front of P1 and behind every sampling chunk (r03: the disassembly shows vmcnt(3)/(2)/(1)/(0)
+  //           next to the hand-placed vmcnt(11)).  Front-loaded, the youngest piece is >= 4 MFMA blocks (~1600 cycles) old at
+  //           any such wait.  (Issuing these loads by inline asm instead - invisible like the DMA - is NOT an option: the
+  //           register allocator treats the destination as written at the asm statement and may copy or reuse it before the
+  //           data lands; r03b faulted exactly that way.)
+  auto dma_slot = [&](bool front, int b, int k) __attribute__((always_inline)) {
+    if (front) {
+      if (b < 4) {
+        if (k == 3) dma(3 * b, 3 * b + 1);
+        if (k == 6) dma(3 * b + 1, 3 * b + 2);
+        if (k == 8) dma(3 * b + 2, 3 * b + 3);
+      }
+    } else {
+      if (k == 3) dma(b, b + 1);
+      if (k == 8 && b < 4) dma(8 + b, 9 + b);
+    }
+  };
+  // hand-over wait in front of a stage's last block: everything but the pieces of the stage being requested has landed
+  // (spread: 11 of them issued by then; front: all 12)
+  auto wait_hand = [&](bool front) __attribute__((always_inline)) {
+    if (front) __builtin_amdgcn_s_waitcnt(0x0F7C);             // vmcnt(12)
+    else __builtin_amdgcn_s_waitcnt(0x0F7B);                   // vmcnt(11)
   };
 
   // fragment reads (per-lane base + slot base + compile-time offsets)
@@ -442,8 +503,7 @@ k_layer(LayerArgs la) {
         if (k == 5 && nb) w[1][1] = frag1(slot, 1, 1, b + 1);
         if (k == 10 && nb) w[0][0] = frag1(slot, 0, 0, b + 1);
         if (k == 11 && nb) w[1][0] = frag1(slot, 0, 1, b + 1);
-        if (k == 3) dma(b, b + 1);
-        if (k == 8 && b < 4) dma(8 + b, 9 + b);
+        dma_slot(true, b, k);                                  // (only P3's split-K sampling stage runs here)
       };
       DDP_LYR_BLOCK2(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], xa[kb1][0], xa[kb1][1], xa[kb1][2], fill)
     }
@@ -460,7 +520,8 @@ k_layer(LayerArgs la) {
   // vmcnt(11)); nothing reads stage q's ring slot after that barrier, because the last block's fragment re-reads fetch
   // block 0 of stage q+1 instead - so the slot may be overwritten by stage q+3's DMA as before, and stage q+1 starts with
   // its operands already in registers.
-  auto tall_pair = [&](f32x16& a0, f32x16& a1) __attribute__((always_inline)) {
+  auto tall_pair = [&](f32x16& a0, f32x16& a1, auto frontc) __attribute__((always_inline)) {
+    constexpr bool front = decltype(frontc)::value != 0;
     u32x4 w[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -477,7 +538,7 @@ k_layer(LayerArgs la) {
         const int rs = hand ? nslot : slot, rb = hand ? 0 : b + 1;
         const int kb = s1 * 8 + b;
         if (hand) {
-          __builtin_amdgcn_s_waitcnt(0x0F7B);                   // vmcnt(11)
+          wait_hand(front);
           __syncthreads();
         }
         auto fill = [&](auto kc) __attribute__((always_inline)) {
@@ -488,8 +549,7 @@ k_layer(LayerArgs la) {
           if (k == 5 && (nb || hand)) w[1][1] = frag1(rs, 1, 1, rb);
           if (k == 10 && (nb || hand)) w[0][0] = frag1(rs, 0, 0, rb);
           if (k == 11 && (nb || hand)) w[1][0] = frag1(rs, 0, 1, rb);
-          if (k == 3) dma(b, b + 1);
-          if (k == 8 && b < 4) dma(8 + b, 9 + b);
+          dma_slot(front, b, k);
         };
         DDP_LYR_BLOCK(a0, a1, xa[kb][0], xa[kb][1], xa[kb][2], fill)
       }
@@ -557,7 +617,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         bias_init(lg[c], c);
-        tall_pair(lg[c][0], lg[c][1]);
+        tall_pair(lg[c][0], lg[c][1], I1);
       }
       const int m = m_base + j;
       const bool valid = m < M;
@@ -774,10 +834,19 @@ k_layer(LayerArgs la) {
     if constexpr (MODE != 4 && MODE != 3) {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
+    // MODE 0: the attention output arrives as fp32 fragments (la.Sf): per stage (32 channels = tile t) four quads
+    constexpr bool SF = (MODE == 0) && (DDP_S_F32 != 0);
+    f32x4 sf[4], sh[2];
+    const float* sfp = la.Sf + grp * 8192 + lane * 4;
+    if constexpr (SF) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int g = 0; g < 4; ++g) sf[g] = *reinterpret_cast<const f32x4*>(sfp + g * 256);
+    } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sc[ks][c] = *reinterpret_cast<const u32x4*>(ss + (ks * 3 + c) * 1024);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sc[ks][c] = *reinterpret_cast<const u32x4*>(ss + (ks * 3 + c) * 1024);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -794,19 +863,35 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
     DDP_LYR_STAMP_AT(10)                                       // tile start: first fragments issued, bias in, weight fragments read
-    auto p0_stage = [&](int st, auto lastc) __attribute__((always_inline)) {
+    if constexpr (SF) {       // stage 0's two K16 blocks: split with nothing to hide behind, once per tile (packed path)
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = sf[e >> 2][e & 3];
+      split8_packed(xv, sc[0][0], sc[0][1], sc[0][2]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = sf[2 + (e >> 2)][e & 3];
+      split8_packed(xv, sc[1][0], sc[1][1], sc[1][2]);
+    }
+    auto p0_stage = [&](int st, auto lastc, auto firstc) __attribute__((always_inline)) {
       constexpr bool last = decltype(lastc)::value != 0;
+      constexpr bool first = decltype(firstc)::value != 0;
       stage_begin(nxt(nxt(slot)));
       const int nslot = nxt(slot);
+      SplitState spa, spb;      // SF: split of the next stage's K16 block 0 (hand-over block) / of this stage's K16 block 1 (blocks 0..3)
       // the LAST stage has no successor: no fragment fetch (it used to re-fetch stage 7's own operands - six dead
       // loads and 24 registers held under the 48 residual loads in flight, which is what tipped the allocator into
       // spilling one of those residual fragments behind a vmcnt(0))
       if constexpr (!last) {
         const int stn = st + 1;
+        if constexpr (SF) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+          for (int g = 0; g < 4; ++g) sf[g] = *reinterpret_cast<const f32x4*>(sfp + stn * 1024 + g * 256);
+        } else {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sn[ks][c] = *reinterpret_cast<const u32x4*>(ss + ((2 * stn + ks) * 3 + c) * 1024);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -819,7 +904,7 @@ k_layer(LayerArgs la) {
           const int rs = hand ? nslot : slot;
           const int tp2 = hand ? 0 : (tp + 1 < 4 ? tp + 1 : 0), ks2 = hand ? 0 : (tp + 1 < 4 ? ks : ks + 1);
           if (hand) {
-            __builtin_amdgcn_s_waitcnt(0x0F7B);                   // vmcnt(11): the next stage's image and sn have landed
+            wait_hand(true);                                      // the next stage's image and S fragments have landed
             __syncthreads();
           }
           auto fill = [&](auto kc) __attribute__((always_inline)) {
@@ -830,14 +915,26 @@ k_layer(LayerArgs la) {
             if (k == 5 && nb) w[1][1] = frag2(rs, 1, 2 * tp2 + 1, ks2);
             if (k == 10 && nb) w[0][0] = frag2(rs, 0, 2 * tp2, ks2);
             if (k == 11 && nb) w[1][0] = frag2(rs, 0, 2 * tp2 + 1, ks2);
-            if (k == 3) dma(blk, blk + 1);
-            if (k == 8 && blk < 4) dma(8 + blk, 9 + blk);
+            dma_slot(true, blk, k);
+            if constexpr (SF) {
+              // the hand-over block (ks = 1: reads sc[1]) splits the NEXT stage's first K16 block into sc[0]; blocks 0..3
+              // (ks = 0: read sc[0]) split THIS stage's second K16 block into sc[1], one instruction per slot, from the
+              // copies kept at the end of the previous stage
+              if (hand) {
+#pragma unroll
+                for (int op = SPLIT_HAND_LO[k]; op < SPLIT_HAND_LO[k + 1]; ++op) split_op(op, spa, sf[0], sf[1], sc[0]);
+              }
+              if (!first && blk < 4 && k < 11) split_op(blk * 11 + k, spb, sh[0], sh[1], sc[1]);
+            }
           };
           DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2], fill)
         }
       if constexpr (last) {
         wait_vm12();
         __syncthreads();
+      } else if constexpr (SF) {
+        sh[0] = sf[2];
+        sh[1] = sf[3];
       } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -849,9 +946,9 @@ k_layer(LayerArgs la) {
       }
       slot = nxt(slot);
     };
-    p0_stage(0, I0);
+    p0_stage(0, I0, I1);
     DDP_LYR_STAMP_AT(11)                                       // stage 0 (waits for the tile's first fragments)
-    for (int st = 1; st < 6; ++st) p0_stage(st, I0);
+    for (int st = 1; st < 6; ++st) p0_stage(st, I0, I0);
     DDP_LYR_STAMP_AT(12)                                       // stages 1..5
     if constexpr (MODE == 2) {
       // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
@@ -866,8 +963,8 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) xr[t][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
       }
-      p0_stage(6, I0);
-      p0_stage(7, I1);
+      p0_stage(6, I0, I0);
+      p0_stage(7, I1, I0);
       if (la.ubuf) {       // u_0 = W_m . m_0 for the u recursion of the following steps (MODE 4)
         float* ub = la.ubuf + grp * 8192 + lane * 4;
 #pragma unroll
@@ -898,13 +995,13 @@ k_layer(LayerArgs la) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
-    p0_stage(6, I0);
+    p0_stage(6, I0, I0);
     DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
 #pragma unroll
     for (int t = 4; t < 8; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
-    p0_stage(7, I1);
+    p0_stage(7, I1, I0);
 
     DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages
     // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)
@@ -961,7 +1058,7 @@ k_layer(LayerArgs la) {
     for (int hc = 0; hc < 16; ++hc) {
       f32x16 acc1[2];
       bias_init(acc1, hc);
-      tall_pair(acc1[0], acc1[1]);
+      tall_pair(acc1[0], acc1[1], I0);
       DDP_LYR_STAMP_AT(2)                                      // fc1 stage pairs
       // GELU + exact split: the result IS the B operand of fc2 (k-block kb = (tile kb/2, quad pair kb%2)).
       // k-block 0 here; k-block kb+1 in the filler slots of k-block kb's four MFMA blocks: four elements per pair of
@@ -1139,7 +1236,7 @@ k_layer(LayerArgs la) {
       for (int vc = 0; vc < 4; ++vc) {
         f32x16 a[2];
         bias_init(a, 16 + vc);
-        tall_pair(a[0], a[1]);
+        tall_pair(a[0], a[1], I1);
         if (valid) {
           float* dst = la.v_out + vrow * 256 + vc * 64 + 4 * h;
 #pragma unroll
@@ -1167,7 +1264,7 @@ k_layer(LayerArgs la) {
             pos[t][g] = *reinterpret_cast<const f32x4*>(la.py + pi * 96 + col) + *reinterpret_cast<const f32x4*>(la.px + pj * 96 + col);
           }
         if (sc2 == 0) {
-          tall_pair(a[0], a[1]);
+          tall_pair(a[0], a[1], I1);
         } else {                                               // columns 64..95 as one split-K stage: a[0] + a[1]
 #pragma unroll
           for (int r = 0; r < 16; ++r) a[1][r] = 0.f;

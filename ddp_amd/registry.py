@@ -78,14 +78,25 @@ def _build_or_delegate(kind, registry, cfg):
     if inspect.isclass(typ) or typ in registry:
         return registry.build(cfg)
     tried = [f'ddp_amd.{registry.name}']
+    last = None
     for pkg, fn in _foreign_builder(kind):
         tried.append(pkg)
+        # "is the type registered there?" is asked of the toolbox's registry itself; a KeyError raised INSIDE a registered
+        # constructor (missing cfg key, nested build failure) is the caller's error and propagates unchanged
+        import importlib
+        reg = getattr(importlib.import_module(pkg), kind.upper() + 'S', None)
+        known = getattr(reg, 'module_dict', None)
+        if known is not None:
+            if typ in known:
+                return fn(cfg)
+            continue
         try:
             return fn(cfg)
-        except KeyError:
+        except KeyError as e:                     # toolbox without an inspectable registry: keep the cause attached
+            last = e
             continue
     raise KeyError(f'{kind} type {typ!r} is not registered in any of {tried}: ddp_amd implements the DDP hot path only - '
-                   f'build the {kind} with the host toolbox (mmseg / depth) or pass a constructed nn.Module')
+                   f'build the {kind} with the host toolbox (mmseg / depth) or pass a constructed nn.Module') from last
 
 
 def build_backbone(cfg):
@@ -152,3 +163,20 @@ def register_into_mmseg():
         DH.register_module(name='DeformableHeadWithTime', force=True, module=DepthDeformableHeadWithTime)
         touched.append('depth')
     return touched
+
+
+def register_into_mmdet3d():
+    """Register the MI355X BEV classes under the REFERENCE's names in an importable BEVFusion-style ``mmdet3d``
+    (bev/mmdet3d/models/fusion_models/ddp.py:65-66 ``@FUSIONMODELS.register_module() class DDP``;
+    bev/mmdet3d/models/heads/segm/deformable_head_with_time.py ``@HEADS.register_module() class DeformableHeadWithTime``),
+    force=True, so that ``type='DDP'`` / ``type='DeformableHeadWithTime'`` in the bev configs resolve to the HIP path.
+    Only the sampling loop is replaced: the sensor encoders / fuser / BEV decoder of ``BEVFusion`` are out of scope
+     and stay the toolbox's.  Returns the list of registries touched (empty when mmdet3d is not importable)."""
+    try:
+        from mmdet3d.models.builder import FUSIONMODELS as MF, HEADS as MH
+    except ImportError:
+        return []
+    from .bev.ddp import DDP as BevDDP, BEVDeformableHeadWithTime
+    MF.register_module(name='DDP', force=True, module=BevDDP)
+    MH.register_module(name='DeformableHeadWithTime', force=True, module=BEVDeformableHeadWithTime)
+    return ['mmdet3d.FUSIONMODELS', 'mmdet3d.HEADS']

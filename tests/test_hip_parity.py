@@ -330,6 +330,7 @@ def test_aug_epilogue_full_size_and_errors():
     from ddp_amd.engine import seg_aug_postprocess, seg_postprocess
     from ddp_amd import _lib
     from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
     ori = (512, 683)
     augs = []
     for i, s in enumerate((0.5, 1.0, 1.5)):

@@ -305,3 +305,62 @@ def test_bench_gpus_flag_is_not_silently_ignored():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=600)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
+
+
+def _stub_toolbox(monkeypatch, pkg, registries):
+    """a minimal importable ``<pkg>.models.builder`` with mmcv-style registries (module_dict, register_module(force=))"""
+    import sys
+    import types
+
+    class Reg:
+        def __init__(self):
+            self.module_dict = {}
+
+        def register_module(self, name=None, force=False, module=None):
+            if name in self.module_dict and not force:
+                raise KeyError(name)
+            self.module_dict[name] = module
+            return module
+
+        def build(self, cfg):
+            args = dict(cfg)
+            return self.module_dict[args.pop('type')](**args)
+
+    top, models, builder = types.ModuleType(pkg), types.ModuleType(pkg + '.models'), types.ModuleType(pkg + '.models.builder')
+    regs = {}
+    for name in registries:
+        regs[name] = Reg()
+        setattr(builder, name, regs[name])
+    top.models, models.builder = models, builder
+    for n, m in ((pkg, top), (pkg + '.models', models), (pkg + '.models.builder', builder)):
+        monkeypatch.setitem(sys.modules, n, m)
+    return builder, regs
+
+
+def test_register_into_mmdet3d_under_the_reference_names(monkeypatch):
+    """bev/mmdet3d/models/fusion_models/ddp.py:65-66 registers ``DDP`` in FUSIONMODELS and the head as
+    ``DeformableHeadWithTime`` in HEADS: ``register_into_mmdet3d`` puts the HIP classes under exactly those names."""
+    assert ddp_amd.register_into_mmdet3d() == [] or True          # without mmdet3d: nothing to touch, no error
+    builder, regs = _stub_toolbox(monkeypatch, 'mmdet3d', ['FUSIONMODELS', 'HEADS'])
+    regs['FUSIONMODELS'].module_dict['DDP'] = object               # the reference's class is already registered
+    assert ddp_amd.register_into_mmdet3d() == ['mmdet3d.FUSIONMODELS', 'mmdet3d.HEADS']
+    assert regs['FUSIONMODELS'].module_dict['DDP'] is ddp_amd.BEVDDP
+    assert regs['HEADS'].module_dict['DeformableHeadWithTime'] is ddp_amd.BEVDeformableHeadWithTime
+
+
+def test_backbone_constructor_keyerror_is_not_swallowed(monkeypatch):
+    """a KeyError raised INSIDE a registered backbone constructor of the host toolbox must surface as it is,
+    not be re-reported as 'type not registered'."""
+    builder, regs = _stub_toolbox(monkeypatch, 'mmseg', ['BACKBONES'])
+
+    class Broken(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            raise KeyError('embed_dims')
+
+    regs['BACKBONES'].module_dict['BrokenNet'] = Broken
+    builder.build_backbone = regs['BACKBONES'].build
+    with pytest.raises(KeyError, match='embed_dims'):
+        ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='BrokenNet')))
+    with pytest.raises(KeyError, match='NoSuchNet.*host toolbox'):
+        ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='NoSuchNet')))
