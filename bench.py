@@ -577,14 +577,17 @@ def main():
             return (time.perf_counter() - t1) / reps * 1e3, r
         t_fpn, f_out = timed(lambda: fpn(lv))
         t_msm, _ = timed(lambda: msm(list(f_out)))
+        # the two as the segmentor runs them: one fused C entry (ddp_amd.NeckChain, the container built from the config's neck list)
+        chain = ddp_amd.NeckChain(fpn, msm)
+        t_neck, _ = timed(lambda: chain(lv))
         t_post, _ = timed(lambda: seg_postprocess(out, (4 * hh, 4 * wh)))
         # The backbone is out of scope and stays PyTorch-ROCm (SURVEY §8d asks for the end-to-end split beside the loop number):
         # a torch stand-in with the dense layers of Swin-T (depths 2-2-6-2, C = 96..768: LayerNorm, qkv / proj / MLP linears,
         # GELU, patch merging; the 7x7 window attention products - 1..8 % of a block's FLOPs - are left out) on the same
         # 8 x 512 x 1024 batch, fp32 as the reference runs it (rocBLAS).
         t_bb, bb_gflop = swin_t_standin_ms(B, 4 * h, 4 * w, dev, timed)
-        e2e = t_bb + t_fpn + t_msm + ms_per_step + t_post
-        next_rows = {'neck_fpn_ms': round(t_fpn, 3), 'neck_multi_stage_merging_ms': round(t_msm, 3),
+        e2e = t_bb + t_neck + ms_per_step + t_post
+        next_rows = {'neck_fpn_ms': round(t_fpn, 3), 'neck_multi_stage_merging_ms': round(t_msm, 3), 'neck_fused_fpn_msm_ms': round(t_neck, 3),
                      'post_epilogue_ms': round(t_post, 3), 'loop_ms': round(ms_per_step, 3),
                      'backbone_standin_ms': round(t_bb, 3), 'backbone_standin_gflop_per_image': round(bb_gflop, 1),
                      'end_to_end_ms': round(e2e, 3), 'end_to_end_images_per_s': round(B / e2e * 1e3, 2),

@@ -12,9 +12,9 @@ from .decode_heads.deformable_head_with_time import DeformableHeadWithTime  # no
 from .decode_heads.fcn_head_with_time import FCNHeadWithTime  # noqa: F401
 from .depther.ddp import DDP as DepthDDP, DepthDeformableHeadWithTime  # noqa: F401
 from .bev.ddp import DDP as BEVDDP, BEVDeformableHeadWithTime  # noqa: F401
-from .necks import FPN, MultiStageMerging  # noqa: F401
+from .necks import FPN, MultiStageMerging, NeckChain  # noqa: F401
 from .apis import single_gpu_test, multi_gpu_test, collect_results  # noqa: F401
 
 __all__ = ['DDP', 'SelfAlignedDDP', 'DeformableHeadWithTime', 'FCNHeadWithTime', 'DepthDDP', 'DepthDeformableHeadWithTime', 'BEVDDP',
-           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg', 'register_into_mmdet3d',
+           'BEVDeformableHeadWithTime', 'FPN', 'MultiStageMerging', 'NeckChain', 'build_segmentor', 'build_depther', 'build_head', 'register_into_mmseg', 'register_into_mmdet3d',
            'single_gpu_test', 'multi_gpu_test', 'collect_results']

@@ -16,6 +16,7 @@ TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
 FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0, FLAG_GATHER_GUESS_ZERO = 1, 2, 4, 8
+NECK_WEIGHTS_READY = 1
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
 
@@ -77,7 +78,7 @@ MAX_AUGS = 16
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_query_const_workspace', 'ddp_prepare',
            'ddp_prepare_geometry', 'ddp_sample', 'ddp_msda_forward_lds_workspace', 'ddp_msda_forward_lds', 'ddp_seg_aug_postprocess',
            'ddp_x0_trace', 'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
+           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_neck_fpn_msm_workspace', 'ddp_neck_fpn_msm', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
 _libs = {}
 
@@ -125,8 +126,8 @@ def load(path=None):
     lib.ddp_seg_x0_project.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_float, _fp, _fp]
     lib.ddp_seg_postprocess.argtypes = [_fp] + [C.c_int] * 12 + [_fp, _fp]
     lib.ddp_neck_msm_workspace.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
-    lib.ddp_neck_msm.argtypes = [C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp,
-                                 _fp]
+    lib.ddp_neck_msm.argtypes = [C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, _fp,
+                                 _fp, _fp]
     lib.ddp_fcn_head_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     lib.ddp_fcn_head_forward.argtypes = [C.POINTER(DdpFcnConv), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int,
                                          C.c_int, _fp, _fp, _fp]
@@ -134,7 +135,9 @@ def load(path=None):
     lib.ddp_sample_fcn.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpFcnConv), C.c_int, C.c_int,
                                    C.POINTER(DdpStep), _fp, _fp, _fp, _fp, _fp, _fp]
     lib.ddp_neck_fpn_workspace.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(C.c_size_t)]
-    lib.ddp_neck_fpn.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]
+    lib.ddp_neck_fpn.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), C.POINTER(_fp), C.c_int, _fp, _fp]
+    lib.ddp_neck_fpn_msm_workspace.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_neck_fpn_msm.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(_fp), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
     lib.ddp_profile_begin.argtypes = [C.c_int]
     lib.ddp_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ddp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]

@@ -1297,15 +1297,18 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
 
 namespace {
 struct MsmLayout {
-  float* tok[4];
+  // weight region first (independent of batch and map sizes: DDP_NECK_WEIGHTS_READY)
   unsigned short* wsplit;
-  unsigned short* a_sb;
-  float* y;
+  unsigned char* stream[4];   // per level: its 256 x 256 block of the 1x1 conv as 8 wide stage images
+  // activations
+  float* a[4];                // level inputs, fp32 fragment-major
+  float* y[4];                // per-level conv outputs at the level's own resolution (y[0]: the merged map)
   double* partial;
   float* stats;
-  size_t bytes;
+  size_t wbytes, abytes, bytes;
 };
-static int msm_layout(int batch, const int* lh, const int* lw, char* base, MsmLayout* o) {
+// weights are carved from wbase, activations from abase (nullptr: sizes only); o->wbytes / o->abytes = the two region sizes
+static int msm_layout(int batch, const int* lh, const int* lw, char* wbase, char* abase, MsmLayout* o) {
   if (batch < 1 || !lh || !lw) {
     set_error("neck_msm: bad arguments");
     return DDP_E_BADCFG;
@@ -1315,22 +1318,28 @@ static int msm_layout(int batch, const int* lh, const int* lw, char* base, MsmLa
       set_error("neck_msm: level %d has size %dx%d", l, lh[l], lw[l]);
       return DDP_E_BADCFG;
     }
+  char* base = wbase;
   size_t off = 0;
   auto take = [&](size_t nbytes) {
     char* p = base ? base + off : nullptr;
     off += (nbytes + 255) / 256 * 256;
     return p;
   };
-  const size_t M = size_t(batch) * lh[0] * lw[0];
-  const size_t Mp = (M + 255) / 256 * 256;
-  for (int l = 0; l < 4; ++l) o->tok[l] = reinterpret_cast<float*>(take(size_t(batch) * lh[l] * lw[l] * 256 * sizeof(float)));
-  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 1024 * 2));
-  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 1024 * 3 * 2));
-  o->y = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
+  o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 256 * 2));
+  for (int l = 0; l < 4; ++l) o->stream[l] = reinterpret_cast<unsigned char*>(take(size_t(8) * b3_stage_bytes()));
+  o->wbytes = off;
+  base = abase;
+  off = 0;
+  for (int l = 0; l < 4; ++l) {
+    const size_t M = size_t(batch) * lh[l] * lw[l], Mp = (M + 255) / 256 * 256;
+    o->a[l] = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
+    o->y[l] = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
+  }
   const size_t chunks = (size_t(lh[0]) * lw[0] + 255) / 256;
   o->partial = reinterpret_cast<double*>(take(size_t(batch) * chunks * 64 * sizeof(double)));
   o->stats = reinterpret_cast<float*>(take(size_t(batch) * 64 * sizeof(float)));
-  o->bytes = off;
+  o->abytes = off;
+  o->bytes = o->wbytes + o->abytes;
   return DDP_OK;
 }
 }  // namespace
@@ -1341,13 +1350,42 @@ int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, si
     return DDP_E_NULL;
   }
   MsmLayout o;
-  DDP_TRY(msm_layout(batch, level_h, level_w, nullptr, &o));
+  DDP_TRY(msm_layout(batch, level_h, level_w, nullptr, nullptr, &o));
   *bytes = o.bytes;
   return DDP_OK;
 }
 
+namespace {
+// the merging itself on fp32 fragment-major level inputs a[0..3] (see ddp_neck_msm)
+int msm_core(const float* const* a_blk, const int* level_h, const int* level_w, int batch, const float* d_conv_w, const float* d_gn_w,
+             const float* d_gn_b, int align_corners, int flags, float* d_out, const MsmLayout& o, hipStream_t st) {
+  const int N = level_h[0] * level_w[0];
+  if (!(flags & DDP_NECK_WEIGHTS_READY))
+    for (int l = 0; l < 4; ++l) {
+      DDP_TRY(launch_split_weights(d_conv_w + 256 * l, 1024, 256, 256, o.wsplit, st));
+      DDP_TRY(launch_build_stages(o.wsplit, size_t(256) * 256, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.stream[l], st));
+    }
+  SgemmProblem pr[4];
+  for (int l = 0; l < 4; ++l) {
+    pr[l].A = a_blk[l];
+    pr[l].out = o.y[l];
+    pr[l].stream = o.stream[l];
+    pr[l].M = batch * level_h[l] * level_w[l];
+    pr[l].ns = 8;
+    pr[l].conv_h = pr[l].conv_w = 0;
+    pr[l].gn_partial = nullptr;                            // (GroupNorm acts on the SUM of the resized level outputs)
+    pr[l].gn_N = 0;
+  }
+  DDP_TRY(launch_b3_sgemm(pr, 4, 0, 0, st));               // all four levels in one persistent launch
+  const float* yl[3] = {o.y[1], o.y[2], o.y[3]};
+  DDP_TRY(launch_msm_sum_blk(o.y[0], yl, level_h + 1, level_w + 1, batch, level_h[0], level_w[0], align_corners ? 1 : 0, st));
+  DDP_TRY(launch_gn_stats_blk(o.y[0], o.partial, o.stats, batch, N, 1e-5f, st));
+  return launch_gn_apply_nchw_blk(o.y[0], o.stats, d_gn_w, d_gn_b, d_out, batch, N, st);
+}
+}  // namespace
+
 int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* level_w, int batch, const float* d_conv_w,
-                 const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out, void* d_workspace,
+                 const float* d_gn_w, const float* d_gn_b, int align_corners, int flags, float* d_out, void* d_workspace,
                  void* stream) {
   if (!d_levels) {
     set_error("levels is NULL");
@@ -1359,77 +1397,79 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
   DDP_TRY(check_ptr(d_gn_b, "gn bias"));
   DDP_TRY(check_ptr(d_out, "out"));
   DDP_TRY(check_ptr(d_workspace, "workspace"));
-  MsmLayout o;
-  DDP_TRY(msm_layout(batch, level_h, level_w, static_cast<char*>(d_workspace), &o));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int N = level_h[0] * level_w[0];
-  const int M = batch * N;
-  MsmArgs a;
-  for (int l = 0; l < 4; ++l) {
-    DDP_TRY(launch_nchw_to_tok(d_levels[l], o.tok[l], batch, 256, level_h[l] * level_w[l], st));
-    a.level[l] = o.tok[l];
-    a.lh[l] = level_h[l];
-    a.lw[l] = level_w[l];
+  if (flags & ~DDP_NECK_WEIGHTS_READY) {
+    set_error("neck_msm: unknown flags 0x%x", flags);
+    return DDP_E_BADCFG;
   }
-  a.h = level_h[0];
-  a.w = level_w[0];
-  a.rows = M;
-  a.align = align_corners ? 1 : 0;
-  a.out_sb = o.a_sb;
-  DDP_TRY(launch_msm_resize_sb(a, st));
-  DDP_TRY(launch_split_weights(d_conv_w, 1024, 256, 1024, o.wsplit, st));
-  SplitW w;
-  w.p = o.wsplit;
-  w.comp_stride = size_t(256) * 1024;
-  DDP_TRY(launch_b3_linear(o.a_sb, w, nullptr, nullptr, 0, 0, 0, o.y, 256, M, 256, 1024, st, TAG_GENERIC));
-  return launch_group_norm_nchw(o.y, o.partial, o.stats, d_gn_w, d_gn_b, d_out, batch, N, 1e-5f, st);
+  MsmLayout o;
+  DDP_TRY(msm_layout(batch, level_h, level_w, nullptr, nullptr, &o));
+  DDP_TRY(msm_layout(batch, level_h, level_w, static_cast<char*>(d_workspace), static_cast<char*>(d_workspace) + o.wbytes, &o));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // The 1x1 conv over the concatenation of the four resized levels is linear: it equals the sum over the levels of the
+  // bilinear resize of (that level's 256-column block of the weight applied at the level's OWN resolution).  Levels 1..3 are
+  // 4x / 16x / 64x smaller than level 0, so the contraction shrinks from 4 to 1.33 level-0 maps and the 1024-channel
+  // concatenation (6 KiB per token as a split operand) is never built.
+  for (int l = 0; l < 4; ++l) DDP_TRY(launch_nchw_to_blk(d_levels[l], o.a[l], batch, 256, level_h[l] * level_w[l], st));
+  return msm_core(o.a, level_h, level_w, batch, d_conv_w, d_gn_w, d_gn_b, align_corners, flags, d_out, o, st);
 }
 
 namespace {
 struct FpnLayout {
-  float* lat[4];            // laterals, token-major (B, N_l, 256)
-  float *tok, *y, *wpack, *stats;
-  unsigned short *a_sb, *wsplit;
-  double* partial;
-  size_t bytes;
+  // weight region first (sizes depend on the level channels only: DDP_NECK_WEIGHTS_READY)
+  float* wpack;
+  unsigned short* wsplit;
+  unsigned char* lat_stream[4];   // lateral 1x1 conv: C_l / 32 wide stage images
+  unsigned char* out_stream[4];   // 3x3 output conv: 72 stage images (tap, 32-channel block)
+  // activations, fp32 fragment-major
+  float* a[4];                    // level inputs (C_l channels)
+  float* y[4];                    // lateral conv output, later the 3x3 conv output
+  float* lat[4];                  // laterals after GroupNorm + top-down add
+  double* partial[4];             // per level: GroupNorm partial sums (chunks of 32 tokens when fused into the GEMM, else 256)
+  float* stats[4];
+  size_t wbytes, abytes, bytes;
 };
-static int fpn_layout(const ddp_fpn_level* lv, int batch, char* base, FpnLayout* o) {
+// weights are carved from wbase, activations from abase (nullptr: sizes only); o->wbytes / o->abytes = the two region sizes
+static int fpn_layout(const ddp_fpn_level* lv, int batch, char* wbase, char* abase, FpnLayout* o) {
   if (!lv || batch < 1) {
     set_error("neck_fpn: bad arguments");
     return DDP_E_BADCFG;
   }
+  char* base = wbase;
   size_t off = 0;
   auto take = [&](size_t nbytes) {
     char* p = base ? base + off : nullptr;
     off += (nbytes + 255) / 256 * 256;
     return p;
   };
-  size_t max_tok = 0, max_a = 0, max_w = 0, Mp0 = 0, max_chunks = 0;
+  size_t max_w = 2304;
   for (int l = 0; l < 4; ++l) {
     const ddp_fpn_level& v = lv[l];
-    if (v.h < 1 || v.w < 1 || v.in_channels < 32 || v.in_channels % 32 || v.in_channels > 4096) {
-      set_error("neck_fpn: level %d: %d channels, %dx%d (channels must be a multiple of 32)", l, v.in_channels, v.h, v.w);
+    if (v.h < 1 || v.w < 1 || v.in_channels < 64 || v.in_channels % 32 || v.in_channels > 4096) {
+      set_error("neck_fpn: level %d: %d channels, %dx%d (channels must be a multiple of 32 in [64, 4096])", l, v.in_channels, v.h, v.w);
       return DDP_E_BADCFG;
     }
-    const size_t M = size_t(batch) * v.h * v.w, Mp = (M + 255) / 256 * 256;
-    o->lat[l] = reinterpret_cast<float*>(take(Mp * 256 * 4));
-    const size_t kmax = v.in_channels > 2304 ? v.in_channels : 2304;       // weight rows: lateral C_l, 3x3 conv 9*256
-    const size_t amax = v.in_channels > 256 ? v.in_channels : 256;         // SB operand: lateral C_l, 3x3 conv 256
-    if (M * v.in_channels > max_tok) max_tok = M * v.in_channels;
-    if (Mp * amax > max_a) max_a = Mp * amax;
-    if (kmax > max_w) max_w = kmax;
-    if (Mp > Mp0) Mp0 = Mp;
-    const size_t ch = (size_t(v.h) * v.w + 255) / 256;
-    if (ch > max_chunks) max_chunks = ch;
+    if (size_t(v.in_channels) > max_w) max_w = v.in_channels;
   }
-  o->tok = reinterpret_cast<float*>(take(max_tok * 4));
-  o->a_sb = reinterpret_cast<unsigned short*>(take(max_a * 6));
-  o->y = reinterpret_cast<float*>(take(Mp0 * 256 * 4));
   o->wpack = reinterpret_cast<float*>(take(size_t(256) * max_w * 4));
   o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * max_w * 2));
-  o->partial = reinterpret_cast<double*>(take(size_t(batch) * max_chunks * 64 * sizeof(double)));
-  o->stats = reinterpret_cast<float*>(take(size_t(batch) * 64 * 4));
-  o->bytes = off;
+  for (int l = 0; l < 4; ++l) {
+    o->lat_stream[l] = reinterpret_cast<unsigned char*>(take(size_t(lv[l].in_channels / 32) * b3_stage_bytes()));
+    o->out_stream[l] = reinterpret_cast<unsigned char*>(take(size_t(72) * b3_stage_bytes()));
+  }
+  o->wbytes = off;
+  base = abase;
+  off = 0;
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = lv[l];
+    const size_t M = size_t(batch) * v.h * v.w, Mp = (M + 255) / 256 * 256;
+    o->a[l] = reinterpret_cast<float*>(take(Mp * v.in_channels * 4));
+    o->y[l] = reinterpret_cast<float*>(take(Mp * 256 * 4));
+    o->lat[l] = reinterpret_cast<float*>(take(Mp * 256 * 4));
+    o->stats[l] = reinterpret_cast<float*>(take(size_t(batch) * 64 * 4));
+    o->partial[l] = reinterpret_cast<double*>(take(size_t(batch) * ((size_t(v.h) * v.w + 31) / 32) * 64 * sizeof(double)));
+  }
+  o->abytes = off;
+  o->bytes = o->wbytes + o->abytes;
   return DDP_OK;
 }
 }  // namespace
@@ -1440,55 +1480,157 @@ int ddp_neck_fpn_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes
     return DDP_E_NULL;
   }
   FpnLayout o;
-  DDP_TRY(fpn_layout(levels, batch, nullptr, &o));
+  DDP_TRY(fpn_layout(levels, batch, nullptr, nullptr, &o));
   *bytes = o.bytes;
   return DDP_OK;
 }
 
-int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, void* d_workspace,
+namespace {
+// d_out != nullptr: the four outputs as NCHW tensors; else they stay fp32 fragment-major in o.lat[l] (consumed by msm_core)
+int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, int flags, const FpnLayout& o,
+             hipStream_t st) {
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[l];
+    DDP_TRY(check_ptr(d_in[l], "level input"));
+    if (d_out) DDP_TRY(check_ptr(d_out[l], "level output"));
+    DDP_TRY(check_ptr(v.lat_w, "lateral weight"));
+    DDP_TRY(check_ptr(v.out_w, "fpn conv weight"));
+  }
+  // weights -> stage images of the stream GEMM (once per set of weights: DDP_NECK_WEIGHTS_READY skips this)
+  if (!(flags & DDP_NECK_WEIGHTS_READY))
+    for (int l = 0; l < 4; ++l) {
+      const ddp_fpn_level& v = levels[l];
+      const int C = v.in_channels;
+      DDP_TRY(launch_split_weights(v.lat_w, C, 256, C, o.wsplit, st));
+      DDP_TRY(launch_build_stages(o.wsplit, size_t(256) * C, C, 256, 0, 1, C / 32, 0, 2, 1, 0, o.lat_stream[l], st));
+      DDP_TRY(launch_pack_conv3x3_scaled(v.out_w, nullptr, o.wpack, 256, 256, st));
+      DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
+      DDP_TRY(launch_build_stages(o.wsplit, size_t(256) * 2304, 2304, 256, 0, 1, 72, 0, 2, 1, 0, o.out_stream[l], st));
+    }
+  // laterals (fpn.py:167-171): 1x1 conv of all four levels in ONE persistent launch of the stream GEMM (k_layer MODE 5; the
+  // coarse levels have few tiles of many stages: longest tiles first), GroupNorm statistics per level
+  SgemmProblem pr[4];
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[3 - l];
+    DDP_TRY(launch_nchw_to_blk(d_in[3 - l], o.a[3 - l], batch, v.in_channels, v.h * v.w, st));
+    pr[l].A = o.a[3 - l];
+    pr[l].out = o.y[3 - l];
+    pr[l].stream = o.lat_stream[3 - l];
+    pr[l].M = batch * v.h * v.w;
+    pr[l].ns = v.in_channels / 32;
+    pr[l].conv_h = pr[l].conv_w = 0;
+    // GroupNorm partial sums in the GEMM epilogue when a wave's 32 tokens cannot straddle two images
+    pr[l].gn_N = v.h * v.w;
+    pr[l].gn_partial = (v.h * v.w) % 32 == 0 ? o.partial[3 - l] : nullptr;
+  }
+  DDP_TRY(launch_b3_sgemm(pr, 4, 0, 0, st));
+  // GroupNorm + top-down path (:173-185): lat_l = GN(y_l) + nearest_up(lat_{l+1}), coarsest level first, one kernel per level
+  for (int l = 3; l >= 0; --l) {
+    const ddp_fpn_level& v = levels[l];
+    if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    else DDP_TRY(launch_gn_stats_blk(o.y[l], o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    DDP_TRY(launch_gn_apply_add_blk(o.y[l], o.stats[l], v.lat_gn_w, v.lat_gn_b, l < 3 ? o.lat[l + 1] : nullptr, o.lat[l], batch, v.h,
+                                    v.w, l < 3 ? levels[l + 1].h : 1, l < 3 ? levels[l + 1].w : 1, st));
+  }
+  // outputs (:189-191): 3x3 conv as an implicit GEMM (72 stage images = (tap, 32-channel block); the A fragments of a stage
+  // are the fp32 quads of the token shifted by the tap, zero padding), all four levels in one launch, then GroupNorm
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[l];
+    pr[l].A = o.lat[l];
+    pr[l].out = o.y[l];
+    pr[l].stream = o.out_stream[l];
+    pr[l].M = batch * v.h * v.w;
+    pr[l].ns = 72;
+    pr[l].conv_h = v.h;
+    pr[l].conv_w = v.w;
+    pr[l].gn_N = v.h * v.w;
+    pr[l].gn_partial = (v.h * v.w) % 32 == 0 ? o.partial[l] : nullptr;
+  }
+  DDP_TRY(launch_b3_sgemm(pr, 4, 0, 1, st));
+  for (int l = 0; l < 4; ++l) {
+    const ddp_fpn_level& v = levels[l];
+    if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    else DDP_TRY(launch_gn_stats_blk(o.y[l], o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    if (d_out) DDP_TRY(launch_gn_apply_nchw_blk(o.y[l], o.stats[l], v.out_gn_w, v.out_gn_b, d_out[l], batch, v.h * v.w, st));
+    else       // (the laterals are dead once the convolution has run: their buffers take the normalised outputs)
+      DDP_TRY(launch_gn_apply_add_blk(o.y[l], o.stats[l], v.out_gn_w, v.out_gn_b, nullptr, o.lat[l], batch, v.h, v.w, 1, 1, st));
+  }
+  return DDP_OK;
+}
+}  // namespace
+
+int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, int flags, void* d_workspace,
                  void* stream) {
   if (!d_in || !d_out) {
     set_error("neck_fpn: in / out is NULL");
     return DDP_E_NULL;
   }
   DDP_TRY(check_ptr(d_workspace, "workspace"));
+  if (flags & ~DDP_NECK_WEIGHTS_READY) {
+    set_error("neck_fpn: unknown flags 0x%x", flags);
+    return DDP_E_BADCFG;
+  }
   FpnLayout o;
-  DDP_TRY(fpn_layout(levels, batch, static_cast<char*>(d_workspace), &o));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // laterals (fpn.py:167-171): 1x1 conv (GEMM, K = C_l) + GroupNorm, kept token-major
-  for (int l = 0; l < 4; ++l) {
-    const ddp_fpn_level& v = levels[l];
-    DDP_TRY(check_ptr(d_in[l], "level input"));
-    DDP_TRY(check_ptr(d_out[l], "level output"));
-    DDP_TRY(check_ptr(v.lat_w, "lateral weight"));
-    DDP_TRY(check_ptr(v.out_w, "fpn conv weight"));
-    const int N = v.h * v.w, M = batch * N, C = v.in_channels;
-    DDP_TRY(launch_nchw_to_sb(d_in[l], o.a_sb, batch, C, N, st));        // NCHW -> split fragments in one pass (no token-major copy)
-    DDP_TRY(launch_split_weights(v.lat_w, C, 256, C, o.wsplit, st));
-    SplitW w;
-    w.p = o.wsplit;
-    w.comp_stride = size_t(256) * C;
-    DDP_TRY(launch_b3_linear_act(o.a_sb, w, nullptr, o.y, 256, M, C, 0, st));
-    DDP_TRY(launch_group_norm_rows(o.y, o.partial, o.stats, v.lat_gn_w, v.lat_gn_b, o.lat[l], batch, N, 1e-5f, st));
+  DDP_TRY(fpn_layout(levels, batch, nullptr, nullptr, &o));
+  DDP_TRY(fpn_layout(levels, batch, static_cast<char*>(d_workspace), static_cast<char*>(d_workspace) + o.wbytes, &o));
+  return fpn_core(levels, batch, d_in, d_out, flags, o, static_cast<hipStream_t>(stream));
+}
+
+// FPN followed by MultiStageMerging, as every DDP config chains them (configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py neck list):
+// the four FPN outputs stay fp32 fragment-major and feed the merging directly - their NCHW form (one write by FPN, one read
+// and re-layout by the merging per level) is never produced.
+int ddp_neck_fpn_msm_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes) {
+  if (!bytes) {
+    set_error("bytes is NULL");
+    return DDP_E_NULL;
   }
-  // top-down path (:173-185): nearest upsample of the coarser lateral, added in place
-  for (int l = 3; l > 0; --l)
-    DDP_TRY(launch_upsample_nearest_add(o.lat[l - 1], o.lat[l], batch, levels[l - 1].h, levels[l - 1].w, levels[l].h,
-                                        levels[l].w, st));
-  // outputs (:189-191): 3x3 conv (implicit GEMM, K = 2304) + GroupNorm -> NCHW
+  FpnLayout f;
+  DDP_TRY(fpn_layout(levels, batch, nullptr, nullptr, &f));
+  int lh[4], lw[4];
   for (int l = 0; l < 4; ++l) {
-    const ddp_fpn_level& v = levels[l];
-    const int N = v.h * v.w, M = batch * N;
-    DDP_TRY(launch_pack_conv3x3_scaled(v.out_w, nullptr, o.wpack, 256, 256, st));
-    DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
-    DDP_TRY(launch_row_to_sb(o.lat[l], 256, o.a_sb, M, 256, st));
-    SplitW w;
-    w.p = o.wsplit;
-    w.comp_stride = size_t(256) * 2304;
-    DDP_TRY(launch_b3_conv3x3(o.a_sb, w, nullptr, o.y, 256, batch, v.h, v.w, 1, 0, st));
-    DDP_TRY(launch_group_norm_nchw(o.y, o.partial, o.stats, v.out_gn_w, v.out_gn_b, d_out[l], batch, N, 1e-5f, st));
+    lh[l] = levels[l].h;
+    lw[l] = levels[l].w;
   }
+  MsmLayout m;
+  DDP_TRY(msm_layout(batch, lh, lw, nullptr, nullptr, &m));
+  *bytes = f.bytes + m.bytes;
   return DDP_OK;
+}
+
+int ddp_neck_fpn_msm(const ddp_fpn_level* levels, int batch, const float* const* d_in, const float* d_msm_conv_w,
+                     const float* d_msm_gn_w, const float* d_msm_gn_b, int align_corners, int flags, float* d_out, void* d_workspace,
+                     void* stream) {
+  if (!d_in) {
+    set_error("neck_fpn_msm: in is NULL");
+    return DDP_E_NULL;
+  }
+  DDP_TRY(check_ptr(d_msm_conv_w, "msm conv weight"));
+  DDP_TRY(check_ptr(d_msm_gn_w, "msm gn weight"));
+  DDP_TRY(check_ptr(d_msm_gn_b, "msm gn bias"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  DDP_TRY(check_ptr(d_workspace, "workspace"));
+  if (flags & ~DDP_NECK_WEIGHTS_READY) {
+    set_error("neck_fpn_msm: unknown flags 0x%x", flags);
+    return DDP_E_BADCFG;
+  }
+  // workspace = [FPN weights | MSM weights | FPN activations | MSM activations]: both weight regions at offsets that do not
+  // depend on the geometry (DDP_NECK_WEIGHTS_READY survives a change of batch / map size)
+  FpnLayout f;
+  DDP_TRY(fpn_layout(levels, batch, nullptr, nullptr, &f));
+  int lh[4], lw[4];
+  for (int l = 0; l < 4; ++l) {
+    lh[l] = levels[l].h;
+    lw[l] = levels[l].w;
+  }
+  MsmLayout m;
+  DDP_TRY(msm_layout(batch, lh, lw, nullptr, nullptr, &m));
+  char* wsb = static_cast<char*>(d_workspace);
+  const size_t fw = f.wbytes, mw = m.wbytes, fa = f.abytes;
+  DDP_TRY(fpn_layout(levels, batch, wsb, wsb + fw + mw, &f));
+  DDP_TRY(msm_layout(batch, lh, lw, wsb + fw, wsb + fw + mw + fa, &m));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DDP_TRY(fpn_core(levels, batch, d_in, nullptr, flags, f, st));
+  return msm_core(f.lat, lh, lw, batch, d_msm_conv_w, d_msm_gn_w, d_msm_gn_b, align_corners, flags, d_out, m, st);
 }
 
 namespace {

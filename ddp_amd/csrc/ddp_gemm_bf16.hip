@@ -95,21 +95,6 @@ int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* 
   return check_launch("b3::k_gemm (conv3x3)");
 }
 
-// same, with an activation on the way out (act: 0 none, 1 GELU, 2 ReLU); N = 256
-int launch_b3_linear_act(const unsigned short* A_sb, const SplitW& w, const float* bias, float* out, int ldo, int M, int K,
-                         int act, hipStream_t st) {
-  EpiRow e;
-  e.add = nullptr;
-  e.ld_add = 0;
-  e.rn = 0;
-  e.n_tok = 0;
-  e.out = out;
-  e.ldo = ldo;
-  e.n_valid = 256;
-  e.gelu = act;
-  const b3::Args ga = make_b3(A_sb, w, bias, M, 256, K);
-  return launch_b3<8, TAG_HEAD>(ga, e, st);
-}
 
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
@@ -338,6 +323,60 @@ int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st) {
   prof_end(TAG_VALUE, st);
   return check_launch("b3::k_layer (layer 0 projections)");
 }
+
+// stream GEMM of the necks (k_layer MODE 5): up to four problems (out = act(A . W^T), 256 outputs each) in ONE persistent launch;
+// the tiles are numbered through the problems in the order given (long tiles first fills the tail best)
+int launch_b3_sgemm(const SgemmProblem* pr, int n, int act, int conv_dil, hipStream_t st) {
+  if (n < 1 || n > 4) {
+    set_error("b3 stream GEMM: %d problems (1..4)", n);
+    return DDP_E_BADCFG;
+  }
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  int tiles = 0;
+  for (int i = 0; i < 4; ++i) {
+    b3::LayerArgs::GemmProblem& g = la.gp[i];
+    if (i >= n) {
+      g.tile0 = 0x7fffffff;
+      g.ns = 2;
+      continue;
+    }
+    if (pr[i].M <= 0) {
+      set_error("b3 stream GEMM: problem %d is empty", i);
+      return DDP_E_BADCFG;
+    }
+    if (pr[i].ns < 2 || (pr[i].conv_h > 0 && pr[i].ns != 72)) {
+      set_error("b3 stream GEMM: %d stages (K = %d) unsupported", pr[i].ns, pr[i].ns * 32);
+      return DDP_E_BADCFG;
+    }
+    g.A = pr[i].A;
+    g.out = pr[i].out;
+    g.stream = pr[i].stream;
+    g.M = pr[i].M;
+    g.ns = pr[i].ns;
+    g.tile0 = tiles;
+    g.conv_h = pr[i].conv_h;
+    g.conv_w = pr[i].conv_w;
+    g.gn_partial = pr[i].gn_partial;
+    g.gn_N = pr[i].gn_N;
+    if (g.gn_partial && (g.gn_N < 32 || g.gn_N % 32 || pr[i].M % g.gn_N)) {
+      set_error("b3 stream GEMM: fused GroupNorm statistics need tokens per image (%d) to be a multiple of 32", g.gn_N);
+      return DDP_E_BADCFG;
+    }
+    tiles += (pr[i].M + b3::LYR_BM - 1) / b3::LYR_BM;
+  }
+  la.g_tiles = tiles;
+  la.M = tiles * b3::LYR_BM;
+  la.g_act = act;
+  la.conv_dil = conv_dil;
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_GENERIC, 5>), int(b3::LYR_LDS_B));
+  const int n_cu = cu_count();
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  hipLaunchKernelGGL((b3::k_layer<TAG_GENERIC, 5>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  return check_launch("b3::k_layer (stream GEMM)");
+}
+size_t b3_stage_bytes() { return size_t(b3::LYR_STAGE_B); }
 
 size_t b3_prologue_stream_bytes() { return size_t(b3::LYR_ST_OUT + b3::LYR_ST_NEXT) * b3::LYR_STAGE_B; }
 size_t b3_layer_stream_bytes() { return size_t(b3::LYR_STAGES) * b3::LYR_STAGE_B; }

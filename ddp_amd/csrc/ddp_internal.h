@@ -94,8 +94,6 @@ int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* b
                      int rn, int n_tok, float* out, int ldo, int M, int N, int K, hipStream_t st, int tag);
 int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* bias, float* out, int ldo, int maps, int h,
                       int wd, int dilation, int act, hipStream_t st);
-int launch_b3_linear_act(const unsigned short* A_sb, const SplitW& w, const float* bias, float* out, int ldo, int M, int K,
-                         int act, hipStream_t st);
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
                         hipStream_t st, int tag);
@@ -181,6 +179,17 @@ struct L0ProjLaunch {
   int n_tok, w;
 };
 int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st);
+// stream GEMM of the necks (k_layer MODE 5): up to four problems in one persistent launch, tiles in the order given
+struct SgemmProblem {
+  const float* A;               // fp32 fragment-major, 32 * ns channels (conv: the 256-channel map)
+  float* out;                   // fp32 fragment-major, 256 channels, rows padded to 128
+  const unsigned char* stream;  // ns wide stage images
+  int M, ns, conv_h, conv_w;    // conv_h > 0: 3x3 convolution view (ns = 72)
+  double* gn_partial;           // optional: fused GroupNorm partial sums [image][token / 32][32 groups][2] (gn_N % 32 == 0)
+  int gn_N;                     // tokens per image
+};
+int launch_b3_sgemm(const SgemmProblem* pr, int n, int act, int conv_dil, hipStream_t st);
+size_t b3_stage_bytes();
 size_t b3_prologue_stream_bytes();
 size_t b3_layer_stream_bytes();
 int b3_layer_bias_floats();
@@ -250,24 +259,20 @@ struct SegPostArgs {
 int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
 int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K, int oh, int ow, int align, unsigned char* seg,
                                float* prob, hipStream_t st);
-struct MsmArgs {
-  const float* level[4];    // token-major (B, N_l, 256)
-  int lh[4], lw[4];
-  int h, w;                 // output grid = level 0
-  int rows;                 // B*h*w
-  int align;
-  unsigned short* out_sb;   // SB, 1024 channels
-};
-int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st);
-int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
-                           int B, int N, float eps, hipStream_t st);
-int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf, int wf, int hc, int wc, hipStream_t st);
+// necks on fp32 fragment-major ("blk") activations - the stream GEMM's operand / result layout
+int launch_nchw_to_blk(const float* in, float* out_blk, int R, int C, int N, hipStream_t st);
+int launch_gn_stats_blk(const float* y_blk, double* partial, float* stats, int B, int N, float eps, hipStream_t st);
+// {mean, rstd} from the per-wave partial sums the stream GEMM wrote (chunks of 32 tokens)
+int launch_gn_final32(const double* partial, float* stats, int B, int N, float eps, hipStream_t st);
+int launch_gn_apply_add_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, const float* coarse_blk,
+                            float* out_blk, int B, int hf, int wf, int hc, int wc, hipStream_t st);
+int launch_gn_apply_nchw_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, float* out, int B, int N,
+                             hipStream_t st);
+int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st);
 // 3x3 convolution as an implicit GEMM (FCNHeadWithTime, FPN): weights packed tap-major, launch_b3_conv3x3
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,
                     const float* conv_bias, const float* film, float* scale, float* shift, hipStream_t st);
-int launch_group_norm_nchw(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
-                           int B, int N, float eps, hipStream_t st);
 // out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st);

@@ -948,74 +948,12 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MultiStageMerging neck (necks/multi_stage_merging.py:40-52): the four FPN levels are resized
-// (bilinear) to the stride-4 grid and concatenated (1024 channels), then down = ConvModule(1024, 256, 1, GN(32)).
-// The concatenation is never materialised in fp32: k_msm_resize_sb writes it directly as the SB operand of the
-// 1x1 conv GEMM; GroupNorm = deterministic two-stage statistics + normalise-and-transpose to NCHW.
+// GroupNorm of the necks: deterministic two-stage statistics (fp64, fixed order) + normalise.  The stream GEMM
+// writes the partial sums itself when it can (k_gn_final32); these kernels cover the other cases and the merged map.
 // ------------------------------------------------------------------------------------------------
-// levels are token-major (B, N_l, 256).  A block owns one 32-token SB group; per level each wave resizes 4 of its
-// tokens into a padded LDS tile (as k_msda_gather_sb), then the block emits that level's 16 K16 blocks.
-__global__ void __launch_bounds__(64 * GSB_WAVES) k_msm_resize_sb(MsmArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[32 * GSB_LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int m_base = blockIdx.x * 32;
-  const int N = a.h * a.w;
-  char* gbase = reinterpret_cast<char*>(a.out_sb) + size_t(blockIdx.x) * 1024 * 192;
-  for (int l = 0; l < 4; ++l) {
-    const int hl = a.lh[l], wl = a.lw[l];
-    const float* lv = a.level[l];
-#pragma unroll
-    for (int it = 0; it < 32 / GSB_WAVES; ++it) {
-      const int jj = wave * (32 / GSB_WAVES) + it;
-      const int m = m_base + jj;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < a.rows) {
-        const int b = m / N, n = m - b * N;
-        const int i = n / a.w, j = n - i * a.w;
-        const UpIdx y = up_index(i, hl, a.h, a.align), x = up_index(j, wl, a.w, a.align);
-        const float* base = lv + size_t(b) * hl * wl * 256 + lane * 4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + size_t(y.i0 * wl + x.i0) * 256);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + size_t(y.i0 * wl + x.i1) * 256);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + size_t(y.i1 * wl + x.i0) * 256);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + size_t(y.i1 * wl + x.i1) * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = bilerp(v00[e], v01[e], v10[e], v11[e], y, x);
-      }
-      *reinterpret_cast<f32x4*>(tile + jj * GSB_LD + lane * 4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16 / GSB_WAVES; ++r) {
-      const int item = r * 64 * GSB_WAVES + threadIdx.x;      // (b, lane') within this level's 256 channels
-      const int b = item >> 6, l2 = item & 63;
-      const int j = l2 & 31, hh = l2 >> 5;
-      const float* src = tile + j * GSB_LD + 16 * b + 4 * hh;
-      const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 8);
-      unsigned short p[3][8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        split3(lo4[u], p[0][u], p[1][u], p[2][u]);
-        split3(hi4[u], p[0][4 + u], p[1][4 + u], p[2][4 + u]);
-      }
-      char* dst = gbase + size_t(l * 16 + b) * 3 * 1024 + l2 * 16;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        uint4 v;
-        v.x = p[c][0] | (unsigned(p[c][1]) << 16);
-        v.y = p[c][2] | (unsigned(p[c][3]) << 16);
-        v.z = p[c][4] | (unsigned(p[c][5]) << 16);
-        v.w = p[c][6] | (unsigned(p[c][7]) << 16);
-        *reinterpret_cast<uint4*>(dst + c * 1024) = v;
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // GroupNorm(32 groups of 8 channels) statistics over a token-major (B, N, 256) tensor, stage 1: block (chunk, b)
 // sums its 256-token chunk; thread = (token row 0..3, channel quad); partial[b][chunk][g] = {sum, sum of squares}
+template <bool BLK>
 __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ y, double* __restrict__ partial, int N,
                                                      int chunks) {
   __shared__ double red[4][32][2];
@@ -1024,7 +962,8 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ y,
   const int n0 = ck * 256, n1 = min(n0 + 256, N);
   double s = 0.0, q = 0.0;
   for (int n = n0 + row; n < n1; n += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t(b) * N + n) * 256 + lane * 4);
+    const size_t mrow = size_t(b) * N + n;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(BLK ? y + blk_off256(int(mrow), lane * 4) : y + mrow * 256 + lane * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s += double(v[e]);
@@ -1059,7 +998,37 @@ __global__ void k_gn_final(const double* __restrict__ partial, float* __restrict
   stats[(b * 32 + g) * 2] = float(mean);
   stats[(b * 32 + g) * 2 + 1] = float(1.0 / sqrt(var + double(eps)));
 }
+// the same from partial sums over chunks of 32 tokens (written by the stream GEMM's epilogue): block = image, thread =
+// (group, one of 32 strided parts), fixed-order sums -> deterministic
+__global__ void __launch_bounds__(1024) k_gn_final32(const double* __restrict__ partial, float* __restrict__ stats, int N, int chunks,
+                                                      float eps) {
+  __shared__ double red[32][32][2];
+  const int b = blockIdx.x, g = threadIdx.x & 31, part = threadIdx.x >> 5;
+  double s = 0.0, q = 0.0;
+  for (int ck = part; ck < chunks; ck += 32) {
+    const double* p = partial + ((size_t(b) * chunks + ck) * 32 + g) * 2;
+    s += p[0];
+    q += p[1];
+  }
+  red[part][g][0] = s;
+  red[part][g][1] = q;
+  __syncthreads();
+  if (part == 0) {
+    double ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      ts += red[k][g][0];
+      tq += red[k][g][1];
+    }
+    const double cnt = double(N) * 8.0;
+    const double mean = ts / cnt;
+    const double var = fmax(tq / cnt - mean * mean, 0.0);
+    stats[(b * 32 + g) * 2] = float(mean);
+    stats[(b * 32 + g) * 2 + 1] = float(1.0 / sqrt(var + double(eps)));
+  }
+}
 // normalise + per-channel affine, token-major (B,N,256) -> NCHW (B,256,N), 64x64 tiles through LDS
+template <bool BLK>
 __global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__ y, const float* __restrict__ stats,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ out, int N) {
@@ -1067,7 +1036,23 @@ __global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  {
+  if constexpr (BLK) {
+    // fragment-major y: thread = (token, channel quad): 16-B reads, 32 consecutive tokens of a quad are 512 B contiguous
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int nn = tx, cq = it * 4 + ty;             // 64 tokens x 16 quads
+      const int n = n0 + nn, c = c0 + cq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) {
+        v = *reinterpret_cast<const f32x4*>(y + blk_off256(int(size_t(b) * N + n), c));
+        const float mean = stats[(b * 32 + (c >> 3)) * 2], rstd = stats[(b * 32 + (c >> 3)) * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * gamma[c + e] + beta[c + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[nn][cq * 4 + e] = v[e];
+    }
+  } else {
     const int c = c0 + tx;
     const float mean = stats[(b * 32 + (c >> 3)) * 2], rstd = stats[(b * 32 + (c >> 3)) * 2 + 1];
     const float ga = gamma[c], be = beta[c];
@@ -1086,43 +1071,98 @@ __global__ void __launch_bounds__(256) k_gn_apply_nchw(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// FPN neck pieces (necks/fpn.py:163-213): lateral 1x1 conv + GN, top-down nearest upsample + add,
-// output 3x3 conv + GN.  The convolutions are bf16x3 GEMMs (the 3x3 ones implicit: b3::k_gemm<..., CONV>); these two kernels are
-// the token-major GroupNorm apply and the top-down step.
+// Neck kernels on fp32 FRAGMENT-MAJOR activations ("blk": per 32-token group [channel tile t][quad g][half][token][4], the
+// layout the stream GEMM (k_layer MODE 5) reads its A operand from and writes its result in; C channels: group stride 32 C
+// floats).  A "piece" p = 4 consecutive channels 4p .. 4p+3 of one token = one 16-B slot; the 32 tokens of a group hold a
+// piece contiguously (512 B), so thread = (group, piece, token) makes every access coalesced.
 // ------------------------------------------------------------------------------------------------
-// out[n][c] = (y[n][c] - mean) * rstd * gamma[c] + beta[c], token-major (B, N, 256) in and out; one wave per token
-__global__ void __launch_bounds__(256) k_gn_apply_rows(const float* __restrict__ y, const float* __restrict__ stats,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ out, int N, int rows) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= rows) return;
-  const int b = m / N;
-  const int g = lane >> 1;                       // 4 channels per lane, 8 per group
-  const float mean = stats[(b * 32 + g) * 2], rstd = stats[(b * 32 + g) * 2 + 1];
-  const f32x4 v = *reinterpret_cast<const f32x4*>(y + size_t(m) * 256 + lane * 4);
-  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
-  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + lane * 4);
-  f32x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * ga[e] + be[e];
-  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = o;
+__device__ __forceinline__ size_t blk_piece_off(int m, int p, int C) {        // floats; p = channel / 4
+  return size_t(m >> 5) * 32 * C + size_t(p) * 128 + (m & 31) * 4;
 }
-// fine[b][i][j][:] += coarse[b][min(floor(i*sy), hc-1)][min(floor(j*sx), wc-1)][:]   (F.interpolate mode='nearest',
-// at::native::nearest_neighbor_compute_source_index with scale = in/out in fp32), token-major, one wave per token
-__global__ void __launch_bounds__(256) k_upsample_nearest_add(float* __restrict__ fine, const float* __restrict__ coarse,
-                                                               int hf, int wf, int hc, int wc, int rows) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+// NCHW (R, C, N) -> blk (rows R*N, C channels, C % 32 == 0): 64 tokens x 64 channels per block through LDS
+__global__ void __launch_bounds__(256) k_nchw_to_blk(const float* __restrict__ in, float* __restrict__ out, int C, int N, int rows) {
+  __shared__ float tile[64][65];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  {
+    const int m = m0 + tx;
+    const int r = m / N, n = m - r * N;
+    const float* src = in + (size_t(r) * C + c0) * N + n;
+    for (int cc = ty; cc < 64; cc += 4) tile[cc][tx] = (m < rows && c0 + cc < C) ? src[size_t(cc) * N] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int nn = tx, cq = it * 4 + ty;                 // 64 tokens x 16 pieces
+    const int c = c0 + cq * 4;
+    if (c >= C) continue;
+    const f32x4 v = {tile[cq * 4][nn], tile[cq * 4 + 1][nn], tile[cq * 4 + 2][nn], tile[cq * 4 + 3][nn]};
+    *reinterpret_cast<f32x4*>(out + blk_piece_off(m0 + nn, c >> 2, C)) = v;      // (rows up to the next multiple of 64: zeros)
+  }
+}
+// FPN top-down step on blk maps (necks/fpn.py:167-185): lat = GroupNorm(y) [+ nearest-upsampled coarser lateral]
+//   out[m][c] = (y[m][c] - mean) * rstd * gamma[c] + beta[c] + coarse[nearest(m)][c]
+__global__ void __launch_bounds__(256) k_gn_apply_add_blk(const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ coarse, float* __restrict__ out, int hf, int wf,
+                                                           int hc, int wc, int rows) {
+  const long idx = long(blockIdx.x) * 256 + threadIdx.x;        // (group, piece, token)
+  const int ml = int(idx & 31), p = int((idx >> 5) & 63), grp = int(idx >> 11);
+  const int m = grp * 32 + ml;
   if (m >= rows) return;
   const int Nf = hf * wf;
   const int b = m / Nf, n = m - b * Nf;
-  const int i = n / wf, j = n - i * wf;
-  const float sy = float(hc) / float(hf), sx = float(wc) / float(wf);
-  const int ic = min(int(floorf(float(i) * sy)), hc - 1), jc = min(int(floorf(float(j) * sx)), wc - 1);
-  f32x4* d = reinterpret_cast<f32x4*>(fine + size_t(m) * 256 + lane * 4);
-  const f32x4 c = *reinterpret_cast<const f32x4*>(coarse + (size_t(b) * hc * wc + ic * wc + jc) * 256 + lane * 4);
-  *d = *d + c;
+  const size_t off = size_t(grp) * 8192 + p * 128 + ml * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+  const float mean = stats[(b * 32 + (p >> 1)) * 2], rstd = stats[(b * 32 + (p >> 1)) * 2 + 1];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + p * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + p * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+  if (coarse) {
+    // F.interpolate(mode='nearest'): src = min(floor(dst * scale), in - 1), scale = in / out in fp32
+    const int i = n / wf, j = n - i * wf;
+    const float sy = float(hc) / float(hf), sx = float(wc) / float(wf);
+    const int ic = min(int(floorf(float(i) * sy)), hc - 1), jc = min(int(floorf(float(j) * sx)), wc - 1);
+    const int mc = b * hc * wc + ic * wc + jc;
+    o = o + *reinterpret_cast<const f32x4*>(coarse + blk_piece_off(mc, p, 256));
+  }
+  *reinterpret_cast<f32x4*>(out + off) = o;
+}
+// MultiStageMerging by linearity: the 1x1 conv over the concatenated, resized levels (necks/multi_stage_merging.py:40-52)
+// = sum over the levels of the bilinear resize of (that level's 256 x 256 block of the conv applied at the level's own
+// resolution): y0 += sum_l resize(y_l), all blk.  (The reference resizes first; both orders are linear maps with the same
+// weights, the results differ by fp32 rounding only.)
+struct MsmSumArgs {
+  float* y0;                // (rows, 256) blk: level 0's conv output in, the merged map out
+  const float* yl[3];       // levels 1..3 conv outputs at their own resolution, blk
+  int lh[3], lw[3];
+  int h, w, rows, align;
+};
+__global__ void __launch_bounds__(256) k_msm_sum_blk(MsmSumArgs a) {
+  const long idx = long(blockIdx.x) * 256 + threadIdx.x;
+  const int ml = int(idx & 31), p = int((idx >> 5) & 63), grp = int(idx >> 11);
+  const int m = grp * 32 + ml;
+  if (m >= a.rows) return;
+  const int N = a.h * a.w;
+  const int b = m / N, n = m - b * N;
+  const int i = n / a.w, j = n - i * a.w;
+  const size_t off = size_t(grp) * 8192 + p * 128 + ml * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(a.y0 + off);
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const int hl = a.lh[l], wl = a.lw[l];
+    const UpIdx y = up_index(i, hl, a.h, a.align), x = up_index(j, wl, a.w, a.align);
+    const int mb = b * hl * wl;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(a.yl[l] + blk_piece_off(mb + y.i0 * wl + x.i0, p, 256));
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(a.yl[l] + blk_piece_off(mb + y.i0 * wl + x.i1, p, 256));
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(a.yl[l] + blk_piece_off(mb + y.i1 * wl + x.i0, p, 256));
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(a.yl[l] + blk_piece_off(mb + y.i1 * wl + x.i1, p, 256));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += bilerp(v00[e], v01[e], v10[e], v11[e], y, x);
+  }
+  *reinterpret_cast<f32x4*>(a.y0 + off) = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1613,18 +1653,6 @@ int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K,
   hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
   return check_launch("k_seg_aug_postprocess");
 }
-int launch_msm_resize_sb(const MsmArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_msm_resize_sb, dim3(cdiv(a.rows, 32)), dim3(64 * GSB_WAVES), 0, st, a);
-  return check_launch("k_msm_resize_sb");
-}
-int launch_group_norm_nchw(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
-                           int B, int N, float eps, hipStream_t st) {
-  const int chunks = cdiv(N, 256);
-  hipLaunchKernelGGL(k_gn_partial, dim3(chunks, B), dim3(256), 0, st, y, partial, N, chunks);
-  hipLaunchKernelGGL(k_gn_final, dim3(B), dim3(32), 0, st, partial, stats, N, chunks, eps);
-  hipLaunchKernelGGL(k_gn_apply_nchw, dim3(cdiv(N, 64), 4, B), dim3(256), 0, st, y, stats, gamma, beta, out, N);
-  return check_launch("group_norm_nchw");
-}
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
                               int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {
   constexpr int TH = 8, TW = 16, NT = GL_THREADS;
@@ -1667,18 +1695,47 @@ int launch_sb_to_row(const unsigned short* in_sb, float* out, int rows, int C, h
   hipLaunchKernelGGL(k_sb_to_row, dim3(cdiv(long(rows) * (C / 8), 256)), dim3(256), 0, st, in_sb, out, rows, C);
   return check_launch("k_sb_to_row");
 }
-int launch_group_norm_rows(const float* y, double* partial, float* stats, const float* gamma, const float* beta, float* out,
-                           int B, int N, float eps, hipStream_t st) {
-  const int chunks = cdiv(N, 256);
-  hipLaunchKernelGGL(k_gn_partial, dim3(chunks, B), dim3(256), 0, st, y, partial, N, chunks);
-  hipLaunchKernelGGL(k_gn_final, dim3(B), dim3(32), 0, st, partial, stats, N, chunks, eps);
-  hipLaunchKernelGGL(k_gn_apply_rows, dim3(cdiv(B * N, 4)), dim3(256), 0, st, y, stats, gamma, beta, out, N, B * N);
-  return check_launch("group_norm_rows");
+int launch_nchw_to_blk(const float* in, float* out_blk, int R, int C, int N, hipStream_t st) {
+  const long rows = long(R) * N;
+  hipLaunchKernelGGL(k_nchw_to_blk, dim3(cdiv(rows, 64), cdiv(C, 64)), dim3(256), 0, st, in, out_blk, C, N, int(rows));
+  return check_launch("k_nchw_to_blk");
 }
-int launch_upsample_nearest_add(float* fine, const float* coarse, int B, int hf, int wf, int hc, int wc, hipStream_t st) {
+int launch_gn_stats_blk(const float* y_blk, double* partial, float* stats, int B, int N, float eps, hipStream_t st) {
+  const int chunks = cdiv(N, 256);
+  hipLaunchKernelGGL(k_gn_partial<true>, dim3(chunks, B), dim3(256), 0, st, y_blk, partial, N, chunks);
+  hipLaunchKernelGGL(k_gn_final, dim3(B), dim3(32), 0, st, partial, stats, N, chunks, eps);
+  return check_launch("gn_stats_blk");
+}
+int launch_gn_final32(const double* partial, float* stats, int B, int N, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_gn_final32, dim3(B), dim3(1024), 0, st, partial, stats, N, N / 32, eps);
+  return check_launch("k_gn_final32");
+}
+int launch_gn_apply_add_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, const float* coarse_blk,
+                            float* out_blk, int B, int hf, int wf, int hc, int wc, hipStream_t st) {
   const int rows = B * hf * wf;
-  hipLaunchKernelGGL(k_upsample_nearest_add, dim3(cdiv(rows, 4)), dim3(256), 0, st, fine, coarse, hf, wf, hc, wc, rows);
-  return check_launch("k_upsample_nearest_add");
+  hipLaunchKernelGGL(k_gn_apply_add_blk, dim3(cdiv(long(cdiv(rows, 32)) * 2048, 256)), dim3(256), 0, st, y_blk, stats, gamma, beta,
+                     coarse_blk, out_blk, hf, wf, hc, wc, rows);
+  return check_launch("k_gn_apply_add_blk");
+}
+int launch_gn_apply_nchw_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, float* out, int B, int N,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(k_gn_apply_nchw<true>, dim3(cdiv(N, 64), 4, B), dim3(256), 0, st, y_blk, stats, gamma, beta, out, N);
+  return check_launch("k_gn_apply_nchw<blk>");
+}
+int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st) {
+  MsmSumArgs a;
+  a.y0 = y0;
+  for (int l = 0; l < 3; ++l) {
+    a.yl[l] = yl[l];
+    a.lh[l] = lh[l];
+    a.lw[l] = lw[l];
+  }
+  a.h = h;
+  a.w = w;
+  a.rows = B * h * w;
+  a.align = align;
+  hipLaunchKernelGGL(k_msm_sum_blk, dim3(cdiv(long(cdiv(a.rows, 32)) * 2048, 256)), dim3(256), 0, st, a);
+  return check_launch("k_msm_sum_blk");
 }
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_conv3x3_scaled, dim3(cdiv(long(cout) * 9 * cin, 256)), dim3(256), 0, st, w, scale, out, cout, cin);

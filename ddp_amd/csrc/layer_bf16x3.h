@@ -106,6 +106,21 @@ struct LayerArgs {
   // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
   // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
   const float* dvec;             // (M) noisy depth map
+  // MODE 5 (stream GEMM of the necks): up to four problems in ONE persistent launch, tiles of 128 tokens numbered through all
+  // of them (gp[i].tile0 = first tile of problem i; unused problems: tile0 = INT_MAX): out (fp32 fragment-major, 256 outputs)
+  // = act(A . W^T), A fp32 fragment-major with 32 * ns channels (split into bf16 pieces in the filler slots, as P0 does with
+  // the attention output), the weights as ns "wide" stage images of the problem's own stream.  conv_h > 0: A is a 256-channel
+  // map of images of conv_h x conv_w tokens and stage st = (tap st / 8, channel block st % 8) of a 3x3 convolution with zero
+  // padding and dilation conv_dil (ns = 72).  The ring's look-ahead follows the block's tile order across problems.
+  struct GemmProblem {
+    const float* A;
+    float* out;
+    const unsigned char* stream;
+    double* gn_partial;      // optional: GroupNorm(32 groups of 8 channels) partial sums of the result, [image][token / 32][group]
+                             // {sum, sum of squares} - one entry per wave; needs gn_N % 32 == 0 (a wave's 32 tokens in one image)
+    int M, ns, tile0, conv_h, conv_w, gn_N;
+  } gp[4];
+  int g_tiles, g_act, conv_dil;
   unsigned long long* stamps;    // -DDDP_LYR_STAMP builds only (scripts/stamp_layer.py): per (block, wave) cycle sums of the phases
 };
 
@@ -327,12 +342,17 @@ k_layer(LayerArgs la) {
   int j = lane & 31;
   int h = lane >> 5;
   const int M = la.M;
-  const int ntiles = (M + LYR_BM - 1) / LYR_BM;
+  const int ntiles = MODE == 5 ? la.g_tiles : (M + LYR_BM - 1) / LYR_BM;
   if (int(blockIdx.x) >= ntiles) return;
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
   unsigned voff0 = unsigned(lane * 16), voff1 = voff0 + 4096, voff2 = voff0 + 8192;   // piece groups of 4 KiB
   const unsigned wave_off = unsigned(wave * 12 * 1024);        // this wave's 12 pieces of every stage
-  const int n_stages = MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
+  auto gp_of = [&](int tile) __attribute__((always_inline)) {          // MODE 5: problem of a tile (uniform)
+    return (tile >= la.gp[1].tile0 ? 1 : 0) + (tile >= la.gp[2].tile0 ? 1 : 0) + (tile >= la.gp[3].tile0 ? 1 : 0);
+  };
+  int fs_tile = blockIdx.x;                                    // MODE 5: the tile whose stages are being fetched
+  int n_stages = MODE == 5 ? la.gp[gp_of(int(blockIdx.x))].ns
+                       : MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
                                                                                     : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
@@ -340,12 +360,23 @@ k_layer(LayerArgs la) {
   auto nxt = [](int s) { return s == LYR_RING - 1 ? 0 : s + 1; };
 
   // once per stage: where the look-ahead comes from / goes to (kept in SGPRs), then advance the stream index
+  const unsigned char* fs_stream = MODE == 5 ? la.gp[gp_of(int(blockIdx.x))].stream : la.stream;
   auto stage_begin = [&](int dslot) __attribute__((always_inline)) {
-    const unsigned long long p = reinterpret_cast<unsigned long long>(la.stream) + size_t(sidx) * LYR_STAGE_B + wave_off;
+    const unsigned long long p = reinterpret_cast<unsigned long long>(fs_stream) + size_t(sidx) * LYR_STAGE_B + wave_off;
     const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(p)), hi = __builtin_amdgcn_readfirstlane(unsigned(p >> 32));
     nb = (static_cast<unsigned long long>(hi) << 32) | lo;
     mb = __builtin_amdgcn_readfirstlane(lds0 + unsigned(dslot * LYR_STAGE_B) + wave_off);
-    sidx = sidx + 1 == n_stages ? 0 : sidx + 1;
+    if (sidx + 1 == n_stages) {
+      sidx = 0;
+      if constexpr (MODE == 5) {         // the stream continues with the block's NEXT tile, possibly of another problem
+        fs_tile += int(gridDim.x);
+        const int pi = gp_of(fs_tile);   // (past the last tile: some problem's stream, fetched and never used)
+        fs_stream = la.gp[pi].stream;
+        n_stages = la.gp[pi].ns;
+      }
+    } else {
+      sidx = sidx + 1;
+    }
   };
   // pieces [i0, i1) of that stage image
   auto dma = [&](int i0, int i1) __attribute__((always_inline)) {
@@ -462,7 +493,8 @@ k_layer(LayerArgs la) {
   dma(0, 12);
   {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + LYR_BIAS_OFF);
-    for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
+    if constexpr (MODE != 5)
+      for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
     if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
     if constexpr (MODE == 0) {
       tab[LYR_T_BO + tid] = la.bo[tid];
@@ -610,6 +642,171 @@ k_layer(LayerArgs la) {
     const char* ss = reinterpret_cast<const char*>(la.S) + grp * 256 * 192 + lane * 16;
     float* qf = la.Q + grp * 8192 + lane * 4;                   // + t * 1024 + g * 256: this lane's accumulator quad (t, g)
 
+    if constexpr (MODE == 5) {
+      // ---- stream GEMM (FPN laterals / 3x3 output convolutions, MultiStageMerging's per-level 1x1 convs): P0's machinery with
+      // a run-time number of wide stages.  The A fragments of a stage are four fp32 quads of this lane's token (for the 3x3
+      // convolution: of the token shifted by the stage's tap; lanes whose source is outside the map take zeros), split into
+      // the three bf16 pieces in the filler slots exactly as P0 splits the attention output.
+      const int pi = gp_of(tile);
+      const int ns = la.gp[pi].ns;
+      const int lt = tile - la.gp[pi].tile0;                   // tile within its problem
+      const int Mp = la.gp[pi].M;
+      int ch = la.gp[pi].conv_h, cw = la.gp[pi].conv_w;
+      asm volatile("" : "+s"(ch), "+s"(cw));                  // (opaque per tile: see P3's index arithmetic)
+      const size_t grp5 = size_t(lt) * (LYR_BM / 32) + wave;
+      const int m = lt * LYR_BM + wave * 32 + j;
+      const bool mvalid = m < Mp;
+      int ci = 0, cj = 0;
+      if (ch > 0) {
+        const int mm = mvalid ? m : Mp - 1;
+        const int n = mm - (mm / (ch * cw)) * (ch * cw);
+        ci = n / cw;
+        cj = n - ci * cw;
+      }
+      const float* abase = la.gp[pi].A;
+      const float* arow = abase + grp5 * size_t(ns) * 1024 + lane * 4;      // plain: this wave's group, 32 * ns channels
+      auto a_load = [&](int st, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+        const float* ap = arow + size_t(st) * 1024;
+        bool ok = true;
+        if (ch > 0) {
+          const int tap = st >> 3;
+          const int dy = (tap / 3 - 1) * la.conv_dil, dx = (tap - (tap / 3) * 3 - 1) * la.conv_dil;
+          ok = mvalid && ci + dy >= 0 && ci + dy < ch && cj + dx >= 0 && cj + dx < cw;
+          const int ms = ok ? m + dy * cw + dx : 0;
+          ap = abase + size_t(ms >> 5) * 8192 + size_t(st & 7) * 1024 + (h * 32 + (ms & 31)) * 4;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = *reinterpret_cast<const f32x4*>(ap + g * 256);
+          dst[g] = v;
+        }
+      };
+      u32x4 sc[2][3];
+      f32x4 sf[4], sh[2];
+      a_load(0, sf);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+      u32x4 w[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[t][c] = frag2(slot, c, t, 0);
+      {
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = sf[e >> 2][e & 3];
+        split8_packed(xv, sc[0][0], sc[0][1], sc[0][2]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = sf[2 + (e >> 2)][e & 3];
+        split8_packed(xv, sc[1][0], sc[1][1], sc[1][2]);
+      }
+      auto g_stage = [&](int st, auto lastc, auto firstc) __attribute__((always_inline)) {
+        constexpr bool last = decltype(lastc)::value != 0;
+        constexpr bool first = decltype(firstc)::value != 0;
+        stage_begin(nxt(nxt(slot)));
+        const int nslot = nxt(slot);
+        SplitState spa, spb;
+        if constexpr (!last) a_load(st + 1, sf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp) {
+            const int blk = ks * 4 + tp;
+            const bool hand = !last && blk == 7;
+            const bool nb = blk + 1 < 8 || hand;
+            const int rs = hand ? nslot : slot;
+            const int tp2 = hand ? 0 : (tp + 1 < 4 ? tp + 1 : 0), ks2 = hand ? 0 : (tp + 1 < 4 ? ks : ks + 1);
+            if (hand) {
+              wait_hand(true);
+              __syncthreads();
+            }
+            auto fill = [&](auto kc) __attribute__((always_inline)) {
+              constexpr int k = decltype(kc)::value;
+              if (k == 0 && nb) w[0][2] = frag2(rs, 2, 2 * tp2, ks2);
+              if (k == 1 && nb) w[1][2] = frag2(rs, 2, 2 * tp2 + 1, ks2);
+              if (k == 4 && nb) w[0][1] = frag2(rs, 1, 2 * tp2, ks2);
+              if (k == 5 && nb) w[1][1] = frag2(rs, 1, 2 * tp2 + 1, ks2);
+              if (k == 10 && nb) w[0][0] = frag2(rs, 0, 2 * tp2, ks2);
+              if (k == 11 && nb) w[1][0] = frag2(rs, 0, 2 * tp2 + 1, ks2);
+              dma_slot(true, blk, k);
+              if (hand) {
+#pragma unroll
+                for (int op = SPLIT_HAND_LO[k]; op < SPLIT_HAND_LO[k + 1]; ++op) split_op(op, spa, sf[0], sf[1], sc[0]);
+              }
+              if (!first && blk < 4 && k < 11) split_op(blk * 11 + k, spb, sh[0], sh[1], sc[1]);
+            };
+            DDP_LYR_BLOCK(acc2[2 * tp], acc2[2 * tp + 1], sc[ks][0], sc[ks][1], sc[ks][2], fill)
+          }
+        if constexpr (last) {
+          wait_vm12();
+          __syncthreads();
+        } else {
+          sh[0] = sf[2];
+          sh[1] = sf[3];
+        }
+        slot = nxt(slot);
+      };
+      g_stage(0, I0, I1);
+      for (int st = 1; st + 1 < ns; ++st) g_stage(st, I0, I0);
+      g_stage(ns - 1, I1, I0);
+      // epilogue: activation (0 none, 2 ReLU), fp32 fragment-major rows out (1-KiB coalesced stores; padding rows of a
+      // problem's last tile are written too - its buffer is padded to whole tiles - and never read)
+      float* qo = la.gp[pi].out + grp5 * 8192 + lane * 4;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+          if (la.g_act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(qo + t * 1024 + g * 256) = v;
+        }
+      if (la.gp[pi].gn_partial) {
+        // GroupNorm statistics of the tile, fused: group G = 4 t + g is this lane's quad (t, g) and its partner half's (lane ^ 32);
+        // fp64 sums over the wave's 32 tokens by a butterfly, lane G keeps group G: one 16-B store per lane of the low half.
+        const int m0w = lt * LYR_BM + wave * 32;               // the wave's first token (all 32 in one image: gn_N % 32 == 0)
+        // value index k = 2 * group + {0: sum, 1: sum of squares}; a transposing butterfly over the 64 lanes: at distance d a
+        // lane keeps the half of its values whose index has bit d set like its own lane id, sends the other half to lane ^ d
+        // and adds what it receives - after six steps lane k holds the total of value k (63 exchanges instead of 64 x 6)
+        double v[64];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            double sv = 0.0, qv = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const double x = double(la.g_act == 2 ? fmaxf(acc2[t][4 * g + e], 0.f) : acc2[t][4 * g + e]);
+              sv += x;
+              qv += x * x;
+            }
+            v[2 * (4 * t + g)] = sv;
+            v[2 * (4 * t + g) + 1] = qv;
+          }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const bool up = (lane & d) != 0;
+#pragma unroll
+          for (int i = 0; i < d; ++i) {
+            const double keep = up ? v[i + d] : v[i];
+            const double send = up ? v[i] : v[i + d];
+            v[i] = keep + __shfl_xor(send, d, 64);
+          }
+        }
+        if (m0w < Mp) {
+          const int nimg = la.gp[pi].gn_N;
+          const int b = m0w / nimg, ck = (m0w - b * nimg) >> 5;
+          la.gp[pi].gn_partial[(size_t(b) * (nimg >> 5) + ck) * 64 + lane] = v[0];
+        }
+      }
+      continue;
+    }
     if constexpr (MODE == 1 || MODE == 4) {
       // ---- seg tail: q fragments of this tile (the layer output), scores = conv_seg(q), per-token update
       load_q_fragments(qf);

@@ -41,6 +41,7 @@ class MultiStageMerging(nn.Module):
         self.down = _Down(sum(in_channels), out_channels)
         nn.init.xavier_uniform_(self.down.conv.weight)
         self._ws = None
+        self._ws_weights = None      # (weights version, workspace pointer) whose stage images the workspace holds
 
     def forward(self, inputs):
         assert len(inputs) == 4
@@ -61,8 +62,11 @@ class MultiStageMerging(nn.Module):
         ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in lv])
         out = torch.empty((B, 256, lv[0].shape[2], lv[0].shape[3]), dtype=torch.float32, device=lv[0].device)
         w = self.down.conv.weight.detach().reshape(256, 1024).contiguous().float()
+        tag = (sum(p._version for p in self.parameters()), self._ws.data_ptr(), w.data_ptr())
+        flags = _lib.NECK_WEIGHTS_READY if tag == self._ws_weights else 0
         _lib.check(lib.ddp_neck_msm(ptrs, lh, lw, B, w.data_ptr(), self.down.gn.weight.detach().float().contiguous().data_ptr(),
-                                    self.down.gn.bias.detach().float().contiguous().data_ptr(), int(bool(self.align_corners)),
+                                    self.down.gn.bias.detach().float().contiguous().data_ptr(), int(bool(self.align_corners)), flags,
                                     out.data_ptr(), self._ws.data_ptr(),
                                     torch.cuda.current_stream(lv[0].device).cuda_stream))
+        self._ws_weights = tag
         return [out]

@@ -36,8 +36,9 @@ class _Conv1x1(nn.Module):
 def _build_neck(neck):
     if neck is None:
         return None
-    if isinstance(neck, (list, tuple)):      # the DDP configs chain FPN -> MultiStageMerging
-        return nn.Sequential(*[build_neck(n) for n in neck])
+    if isinstance(neck, (list, tuple)):      # the DDP configs chain FPN -> MultiStageMerging: one fused C entry (necks/chain.py)
+        from ..necks import NeckChain
+        return NeckChain(*[build_neck(n) for n in neck])
     return build_neck(neck)
 
 

@@ -256,13 +256,18 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
  * d_levels[l] (B,256,h_l,w_l) NCHW; d_conv_w = neck.down.conv.weight (256,1024,1,1); d_gn_w/d_gn_b = neck.down.gn.*;
  * d_out (B,256,h_0,w_0) NCHW.  Workspace from ddp_neck_msm_workspace (caller-owned). */
 int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, size_t* bytes);
+/* flags of the two neck entries: the workspace starts with a weight region (split weight planes as the stage images of the
+ * stream GEMM) whose layout depends on the channel counts only; a caller that runs the same weights again through the same
+ * workspace buffer passes DDP_NECK_WEIGHTS_READY and the weights are not re-packed. */
+#define DDP_NECK_WEIGHTS_READY 1
 int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* level_w, int batch,
-                 const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, float* d_out,
+                 const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, int flags, float* d_out,
                  void* d_workspace, void* stream);
 
 /* FPN neck (necks/fpn.py:163-213) as the DDP configs build it: 4 levels, lateral ConvModule(C_l,256,1,
  * bias=False, GN(32), no act), top-down nearest upsample + add, output ConvModule(256,256,3,padding=1,bias=False,GN(32),
- * no act); num_outs = 4 (no extra levels).  d_in[l] (B,C_l,h_l,w_l) NCHW, C_l % 32 == 0; d_out[l] (B,256,h_l,w_l) NCHW. */
+ * no act); num_outs = 4 (no extra levels).  d_in[l] (B,C_l,h_l,w_l) NCHW, C_l % 32 == 0, 64 <= C_l <= 4096; d_out[l]
+ * (B,256,h_l,w_l) NCHW. */
 typedef struct ddp_fpn_level {
   const float* lat_w;      /* lateral_convs.l.conv.weight (256,C_l,1,1) */
   const float* lat_gn_w;   /* lateral_convs.l.gn.weight / bias (256) */
@@ -273,8 +278,17 @@ typedef struct ddp_fpn_level {
   int in_channels, h, w;
 } ddp_fpn_level;
 int ddp_neck_fpn_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes);
-int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, void* d_workspace,
-                 void* stream);
+int ddp_neck_fpn(const ddp_fpn_level* levels, int batch, const float* const* d_in, float* const* d_out, int flags,
+                 void* d_workspace, void* stream);
+
+/* FPN followed by MultiStageMerging - the neck list of every DDP config (configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py: neck =
+ * [FPN, MultiStageMerging]; the segmentor uses only the merged map): the four FPN outputs stay in the GEMM operand layout and
+ * feed the merging directly; their NCHW form is never produced.  d_in[l] as ddp_neck_fpn, the three MSM parameters as
+ * ddp_neck_msm, d_out (B,256,h_0,w_0) NCHW. */
+int ddp_neck_fpn_msm_workspace(const ddp_fpn_level* levels, int batch, size_t* bytes);
+int ddp_neck_fpn_msm(const ddp_fpn_level* levels, int batch, const float* const* d_in, const float* d_msm_conv_w,
+                     const float* d_msm_gn_w, const float* d_msm_gn_b, int align_corners, int flags, float* d_out,
+                     void* d_workspace, void* stream);
 
 /* FCNHeadWithTime.forward (decode_heads/fcn_head_with_time.py:285-305), eval mode:
  *   x = inputs[0]; for each ConvWithTimeModule: x = ReLU( norm(conv3x3(x)) * (scale + 1) + shift ),

@@ -497,6 +497,23 @@ def test_fpn_then_merging_chain_matches_oracle():
     torch.cuda.synchronize()
     ref = O.neck_multi_stage_merging(list(O.neck_fpn(levels, sdf)), sdm)
     assert max_rel(got.cpu(), ref) < REL
+    # the container the segmentor builds from the config's neck list runs the pair as ONE C entry (ddp_neck_fpn_msm: the FPN
+    # outputs never take their NCHW form): same state_dict keys as nn.Sequential, same result as the member-by-member chain
+    fused = ddp_amd.NeckChain(fpn, msm).cuda().eval()
+    assert fused.fused() and list(fused.state_dict()) == list(chain.state_dict())
+    a = fused([t.cuda() for t in levels])[0]
+    assert max_rel(a.cpu(), ref) < REL and max_rel(a.cpu(), got.cpu()) < 1e-5
+    b = fused([t.cuda() for t in levels])[0]                   # second call: weight region of the workspace re-used
+    assert torch.equal(a, b) and fused._ws_weights is not None
+    with torch.no_grad():                                      # changed weights are re-packed
+        msm.down.gn.bias.add_(0.5)
+    c = fused([t.cuda() for t in levels])[0]
+    assert max_rel(c.cpu(), O.neck_multi_stage_merging(list(O.neck_fpn(levels, sdf)), {k: v.cpu() for k, v in msm.state_dict().items()})) < REL
+    # maps whose token count is not a multiple of 32 (GroupNorm statistics by the separate kernels), odd sizes
+    lv2 = synthetic.make_backbone_levels(1, inc, 13, 19, 4)
+    g2 = fused([t.cuda() for t in lv2])[0]
+    r2 = O.neck_multi_stage_merging(list(O.neck_fpn(lv2, sdf)), {k: v.cpu() for k, v in msm.state_dict().items()})
+    assert max_rel(g2.cpu(), r2) < REL
 
 
 # ---- edge geometry: single-token maps, one layer (no "next layer" projections), the class-count limits ---------------

@@ -53,4 +53,4 @@ def test_gather_fits_three_blocks_per_cu(tmp_path):
         assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0
         assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 85
         assert int(re.search(r'\.amdhsa_group_segment_fixed_size (\d+)', body).group(1)) <= 160 * 1024 // 3
-    assert found == 1
+    assert found == 2          # the SB-output and the fp32-fragment-output instantiation
