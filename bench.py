@@ -663,8 +663,9 @@ def main():
         # itself by this much on the same image when each run takes its own argmax (oracle.reference_drift_seg)
         if task == 'seg' and r == 1 and K > 1:
             try:
+                # (headline workload: both variants; the larger maps: the explicit-tap core only - fp64 costs minutes there)
                 dr = O.reference_drift_seg(x[:1], noise[0], sd, timesteps=K, accumulation=wl['accumulation'], bit_scale=wl['bit_scale'],
-                                           base=ref0, base_decisions=dec0)
+                                           base=ref0, base_decisions=dec0, variants=('taps', 'fp64') if headline else ('taps',))
                 parity['free_running_image0'] = worst0
                 parity['reference_vs_reference'] = {'max_rel': dr['ref_vs_ref'], 'variants': dr['variants']}
                 parity['free_running_within_2x_reference_drift'] = bool(worst0 <= max(1e-3, 2 * dr['ref_vs_ref']))

@@ -73,7 +73,7 @@ for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),
     f = glob.glob(os.path.join(src, pat), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, name))
-for wl in ('city_swin_l_k10_4x1024x2048', 'kitti_depth_k20_16x352x1216', 'bev_fusion_k3_8x200x200'):
+for wl in ('ade_swin_t_k3_1x512x1024', 'city_swin_l_k10_4x1024x2048', 'kitti_depth_k20_16x352x1216', 'bev_fusion_k3_8x200x200'):
     f = glob.glob(os.path.join(src, 'prof_' + wl, '**', '*kernel_stats.csv'), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f'{tag}_{wl}_kernel_stats.csv'))

@@ -18,10 +18,13 @@ fi
 PYTEST_ORDER="python -m pytest tests -m gpu -q -s"
 run_tests() { $PYTEST_ORDER ${KSEL:+"$KSEL"} 2>&1 | grep -v "amdgpu.ids\|^$" > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt; }
 [ "$QUICK" = quick ] || run_tests
-python bench.py --steps 10 --warmup 2 --next-rows > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json; tail -3 $OUT/bench.err
+python bench.py --steps 10 --warmup 2 --next-rows --size-stream 50 > $OUT/bench.json 2> $OUT/bench.err
+cut -c1-2500 $OUT/bench.json; tail -3 $OUT/bench.err
+# the strong-scaling shard of the headline configuration (one image per GPU at 8 GPUs), with kernel stats
+python bench.py --workload ade_swin_t_k3_1x512x1024 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_ade_swin_t_k3_1x512x1024.json 2> $OUT/bench_b1.err
+cut -c1-400 $OUT/bench_ade_swin_t_k3_1x512x1024.json
 REPO=$PWD
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -o ddp -- $BENCH > $REPO/$OUT/prof_run.log 2>&1
 # the rows either side of the loop (FPN, MultiStageMerging, post-loop epilogue) in their own kernel-stats pass
@@ -31,11 +34,12 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/p
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_rd -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_rd.log 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_wr -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_wr.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma -o ddp -- $BENCH > $REPO/$OUT/pmc_mfma.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_ade_swin_t_k3_1x512x1024 -o ddp -- python $REPO/bench.py --workload ade_swin_t_k3_1x512x1024 --steps 20 --warmup 2 --no-cpu-baseline --no-roofline --no-power > $REPO/$OUT/prof_b1.log 2>&1
 # the other BASELINE configurations (per-GPU shards): kernel stats + MFMA-busy counters each
 WLS="city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200"
 [ "$QUICK" = quick ] && WLS=
 for wl in $WLS; do
-  B2="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --workload $wl"
+  B2="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-power --workload $wl"
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_$wl -o ddp -- $B2 > $REPO/$OUT/prof_$wl.log 2>&1
   timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma_$wl -o ddp -- $B2 > $REPO/$OUT/pmc_mfma_$wl.log 2>&1
 done
@@ -48,7 +52,7 @@ done
 # the process-group path of bench.py (RCCL init, 34 MB weight broadcast, replica check by all_gather, barrier, MAX all_reduce)
 # under the launcher at world size 1 - the multi-GPU code path with the one device this box has
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
-    --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --force-dist > $OUT/force_dist_rccl_world1.json 2> $OUT/force_dist_rccl_world1.err
+    --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power --force-dist > $OUT/force_dist_rccl_world1.json 2> $OUT/force_dist_rccl_world1.err
 tail -1 $OUT/force_dist_rccl_world1.json | cut -c1-300
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -30 "$f"
