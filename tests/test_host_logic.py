@@ -364,3 +364,23 @@ def test_backbone_constructor_keyerror_is_not_swallowed(monkeypatch):
         ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='BrokenNet')))
     with pytest.raises(KeyError, match='NoSuchNet.*host toolbox'):
         ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='NoSuchNet')))
+
+
+def test_neck_list_builds_the_fused_chain_with_sequential_keys():
+    """the config's neck list [FPN, MultiStageMerging] (configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py) becomes a
+    ``NeckChain``: an nn.Sequential by state_dict keys (``neck.0.*`` / ``neck.1.*``, as the reference's checkpoints name them)
+    whose forward is one fused C entry on the GPU - and, like everything else here, has no CPU path"""
+    inc = [96, 192, 384, 768]
+    neck = [dict(type='FPN', in_channels=inc, out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32), num_outs=4),
+            dict(type='MultiStageMerging', in_channels=[256] * 4, out_channels=256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32),
+                 act_cfg=None)]
+    model = ddp_amd.build_segmentor(seg_cfg(neck=neck))
+    assert isinstance(model.neck, ddp_amd.NeckChain) and isinstance(model.neck, torch.nn.Sequential) and model.neck.fused()
+    keys = [k for k in model.state_dict() if k.startswith('neck.')]
+    assert 'neck.0.lateral_convs.0.conv.weight' in keys and 'neck.0.fpn_convs.3.gn.bias' in keys and 'neck.1.down.conv.weight' in keys
+    want = torch.nn.Sequential(ddp_amd.FPN(in_channels=inc, out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32), num_outs=4),
+                               ddp_amd.MultiStageMerging([256] * 4, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None))
+    assert [k[len('neck.'):] for k in keys] == list(want.state_dict())
+    levels = synthetic.make_backbone_levels(1, inc, 8, 8, 0)
+    with pytest.raises(_lib.DdpError, match='no CPU path'):
+        model.neck(levels)
