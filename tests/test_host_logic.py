@@ -384,3 +384,51 @@ def test_neck_list_builds_the_fused_chain_with_sequential_keys():
     levels = synthetic.make_backbone_levels(1, inc, 8, 8, 0)
     with pytest.raises(_lib.DdpError, match='no CPU path'):
         model.neck(levels)
+
+
+def test_model_region_of_the_workspace_is_independent_of_the_geometry():
+    """``ddp_query_const_workspace`` (the prefix ``ddp_prepare_geometry`` leaves alone): same bytes for every batch / map size
+    of one model, different for another model; the total workspace grows with the geometry.  Host-side arithmetic only."""
+    lib = _lib.load()
+
+    def sizes(batch, h, w, K=3, ncls=150, flags=0):
+        cfg = _lib.DdpCfg()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.task, cfg.batch, cfg.randsteps, cfg.timesteps, cfg.num_layers = 0, batch, 1, K, 6
+        cfg.num_classes, cfg.feat_channels, cfg.h, cfg.w, cfg.head_h, cfg.head_w = ncls, 256, h, w, h, w
+        cfg.gemm_mode, cfg.flags = _lib.GEMM_BF16X3, flags
+        c, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert lib.ddp_query_const_workspace(ctypes.byref(cfg), ctypes.byref(c)) == 0
+        assert lib.ddp_query_workspace(ctypes.byref(cfg), ctypes.byref(t)) == 0
+        return c.value, t.value
+    c1, t1 = sizes(1, 128, 171)
+    c2, t2 = sizes(8, 128, 256)
+    c3, t3 = sizes(1, 37, 53, flags=_lib.FLAG_RECORD_X0)
+    assert c1 == c2 == c3 and 25e6 < c1 < 80e6            # ~30 MB of split weights + weight streams
+    assert t3 < t1 < t2 and t1 > c1
+    assert sizes(1, 128, 171, K=10)[0] > c1 and sizes(1, 128, 171, ncls=19)[0] != c1
+    cfg = _lib.DdpCfg()
+    assert lib.ddp_query_const_workspace(ctypes.byref(cfg), ctypes.byref(ctypes.c_size_t(0))) == -1     # abi_version 0
+    assert lib.ddp_prepare_geometry(ctypes.byref(cfg), None, None) == -1
+
+
+def test_new_entry_points_validate_on_the_host():
+    """argument checks of the round-3 entries that return before any launch"""
+    lib = _lib.load()
+    n = ctypes.c_size_t(0)
+    assert lib.ddp_msda_forward_lds_workspace(100, 8, 16, ctypes.byref(n)) == -1 and b'multiple' in lib.ddp_last_error()
+    assert lib.ddp_msda_forward_lds_workspace(256, 8, 16, ctypes.byref(n)) == 0 and n.value > 256 * 256 * 4
+    augs = (_lib.DdpSegAug * 1)()
+    seg = ctypes.create_string_buffer(16)
+    assert lib.ddp_seg_aug_postprocess(augs, 0, 1, 19, 4, 4, 0, seg, None, None) == -1
+    assert lib.ddp_seg_aug_postprocess(augs, 17, 1, 19, 4, 4, 0, seg, None, None) == -1
+    assert lib.ddp_seg_aug_postprocess(None, 1, 1, 19, 4, 4, 0, seg, None, None) == -4
+    lv = (_lib.DdpFpnLevel * 4)()
+    for l, c in enumerate([96, 192, 384, 32]):
+        lv[l].in_channels, lv[l].h, lv[l].w = c, 8 >> l or 1, 8 >> l or 1
+    assert lib.ddp_neck_fpn_workspace(lv, 1, ctypes.byref(n)) == -1 and b'64' in lib.ddp_last_error()      # 32 channels: one stage
+    lv[3].in_channels = 768
+    assert lib.ddp_neck_fpn_workspace(lv, 1, ctypes.byref(n)) == 0
+    fpn_bytes = n.value
+    assert lib.ddp_neck_fpn_msm_workspace(lv, 1, ctypes.byref(n)) == 0 and n.value > fpn_bytes
+    assert lib.ddp_profile_read(99, None, None) == -1 and lib.ddp_profile_read(7, None, None) == -1        # unknown tag / no session
