@@ -9,16 +9,11 @@
 // coordinates | 4 attention weights] (the gather runs one head per block); the standalone GEMM epilogue / wave-per-token
 // gathers keep token-major rows of DDP_SAMP_STRIDE floats.  Same size, same workspace slot.
 
-// Build-time variants of the layer kernel / gather pair (same-box A/B builds: scripts/variant_build.sh x -DDDP_S_F32=0):
+// Build-time variant of the layer kernel / gather pair (same-box A/B builds: scripts/variant_build.sh x -DDDP_S_F32=0):
 //   DDP_S_F32          the LDS gather hands the attention output to the layer kernel as fp32 fragments (1 KiB per token) and
 //                      P0 splits it in its filler slots; 0: as SB (1.5 KiB per token, split in the gather)
-//   DDP_LYR_ASM_LOADS  the layer kernel's own global loads are issued by inline asm so that hipcc's s_waitcnt insertion
-//                      cannot put a vmcnt(0) - "wait for the DMA stage just requested" - in front of their first use
 #ifndef DDP_S_F32
 #define DDP_S_F32 1
-#endif
-#ifndef DDP_LYR_ASM_LOADS
-#define DDP_LYR_ASM_LOADS 1
 #endif
 
 namespace ddp {
