@@ -1373,6 +1373,7 @@ int msm_core(const float* const* a_blk, const int* level_h, const int* level_w, 
     pr[l].M = batch * level_h[l] * level_w[l];
     pr[l].ns = 8;
     pr[l].conv_h = pr[l].conv_w = 0;
+    pr[l].bias = nullptr;
     pr[l].gn_partial = nullptr;                            // (GroupNorm acts on the SUM of the resized level outputs)
     pr[l].gn_N = 0;
   }
@@ -1519,6 +1520,7 @@ int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, f
     pr[l].M = batch * v.h * v.w;
     pr[l].ns = v.in_channels / 32;
     pr[l].conv_h = pr[l].conv_w = 0;
+    pr[l].bias = nullptr;
     // GroupNorm partial sums in the GEMM epilogue when a wave's 32 tokens cannot straddle two images
     pr[l].gn_N = v.h * v.w;
     pr[l].gn_partial = (v.h * v.w) % 32 == 0 ? o.partial[3 - l] : nullptr;
@@ -1635,8 +1637,9 @@ int ddp_neck_fpn_msm(const ddp_fpn_level* levels, int batch, const float* const*
 
 namespace {
 struct FcnLayout {
-  float *x0, *x1, *wpack, *film, *aff, *logits;
-  unsigned short *a_sb, *wsplit, *q_sb, *wcls;
+  float *x0, *xb0, *xb1, *wpack, *film, *aff, *logits, *cls_bias;
+  unsigned short *a_sb, *wsplit;
+  unsigned char* stream;     // stage images of the GEMM being run (72 for a 3x3 conv, 8 for conv_seg)
   int ldl;
   size_t bytes;
 };
@@ -1653,15 +1656,16 @@ static int fcn_layout(int maps, int h, int w, int K, char* base, FcnLayout* o) {
   };
   const size_t M = size_t(maps) * h * w, Mp = (M + 255) / 256 * 256;
   o->ldl = (K + 31) / 32 * 32;
-  o->x0 = reinterpret_cast<float*>(take(Mp * 256 * 4));
-  o->x1 = reinterpret_cast<float*>(take(Mp * 256 * 4));
-  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 256 * 6));
+  o->x0 = reinterpret_cast<float*>(take(Mp * 256 * 4));        // row-major input (the sampler's concat-conv writes it)
+  o->xb0 = reinterpret_cast<float*>(take(Mp * 256 * 4));       // fp32 fragment-major activations, ping / pong
+  o->xb1 = reinterpret_cast<float*>(take(Mp * 256 * 4));
+  o->a_sb = reinterpret_cast<unsigned short*>(take(Mp * 256 * 6));   // (SB staging of the sampler's concat-conv input)
   o->wpack = reinterpret_cast<float*>(take(size_t(256) * 2304 * 4));
   o->wsplit = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 2304 * 2));
+  o->stream = reinterpret_cast<unsigned char*>(take(size_t(72) * b3_stage_bytes()));
   o->film = reinterpret_cast<float*>(take(512 * 4));
   o->aff = reinterpret_cast<float*>(take(512 * 4));
-  o->q_sb = reinterpret_cast<unsigned short*>(take(Mp * 256 * 6));
-  o->wcls = reinterpret_cast<unsigned short*>(take(size_t(3) * 256 * 256 * 2));
+  o->cls_bias = reinterpret_cast<float*>(take(256 * 4));
   o->logits = reinterpret_cast<float*>(take(Mp * o->ldl * 4));
   o->bytes = off;
   return DDP_OK;
@@ -1680,12 +1684,20 @@ int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* byte
 }
 
 namespace {
-// FCNHeadWithTime on token-major rows: o.x0 (M,256) in -> o.logits (M, ldl) (fcn_head_with_time.py:285-305, eval mode)
+// FCNHeadWithTime on token-major rows: o.x0 (M,256) in -> o.logits (M, ldl) (fcn_head_with_time.py:285-305, eval mode).  Inside,
+// the activations are fp32 fragment-major and every convolution runs on the persistent stream GEMM (k_layer MODE 5): the 3x3
+// ones as implicit GEMMs of 72 stages with the folded norm x FiLM shift as bias and ReLU in the epilogue, conv_seg as 8 stages
+// with the class rows zero-padded to 256.
 int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
                     int num_classes, const float* d_temb, int maps, int h, int w, const FcnLayout& o, hipStream_t st) {
   const int N = h * w, M = maps * N;
-  float* cur = o.x0;
-  float* nxt = o.x1;
+  DDP_TRY(launch_row_to_blk(o.x0, o.xb0, M, st));
+  float* cur = o.xb0;
+  float* nxt = o.xb1;
+  SgemmProblem pr;
+  pr.gn_partial = nullptr;
+  pr.gn_N = 0;
+  pr.M = M;
   for (int i = 0; i < num_convs; ++i) {
     const ddp_fcn_conv& c = convs[i];
     DDP_TRY(check_ptr(c.conv_w, "conv weight"));
@@ -1701,21 +1713,35 @@ int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, cons
     DDP_TRY(launch_fcn_fold(c.bn_w, c.bn_b, c.bn_mean, c.bn_var, c.bn_eps, c.conv_b, film, o.aff, o.aff + 256, st));
     DDP_TRY(launch_pack_conv3x3_scaled(c.conv_w, o.aff, o.wpack, 256, 256, st));
     DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
-    DDP_TRY(launch_row_to_sb(cur, 256, o.a_sb, M, 256, st));
-    SplitW wsp;
-    wsp.p = o.wsplit;
-    wsp.comp_stride = size_t(256) * 2304;
-    DDP_TRY(launch_b3_conv3x3(o.a_sb, wsp, o.aff + 256, nxt, 256, maps, h, w, dilation, 2, st));
+    DDP_TRY(launch_build_stages(o.wsplit, size_t(256) * 2304, 2304, 256, 0, 1, 72, 0, 2, 1, 0, o.stream, st));
+    pr.A = cur;
+    pr.out = nxt;
+    pr.stream = o.stream;
+    pr.ns = 72;
+    pr.conv_h = h;
+    pr.conv_w = w;
+    pr.bias = o.aff + 256;
+    DDP_TRY(launch_b3_sgemm(&pr, 1, 2, dilation, st));
     float* t = cur;
     cur = nxt;
     nxt = t;
   }
-  DDP_TRY(launch_row_to_sb(cur, 256, o.q_sb, M, 256, st));
-  DDP_TRY(launch_split_weights(d_cls_w, 256, num_classes, 256, o.wcls, st));
-  SplitW wc;
-  wc.p = o.wcls;
-  wc.comp_stride = size_t(num_classes) * 256;
-  return launch_b3_linear(o.q_sb, wc, d_cls_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, num_classes, 256, st, TAG_HEAD);
+  // conv_seg (cls_seg; dropout is the identity in eval mode): 1x1, the class rows zero-padded to the GEMM's 256 outputs
+  DDP_TRY(launch_split_weights(d_cls_w, 256, num_classes, 256, o.wsplit, st));
+  DDP_TRY(launch_build_stages(o.wsplit, size_t(num_classes) * 256, 256, num_classes, 0, 1, 8, 0, 2, 1, 0, o.stream, st));
+  if (hipMemsetAsync(o.cls_bias, 0, 256 * sizeof(float), st) != hipSuccess ||
+      (d_cls_b && hipMemcpyAsync(o.cls_bias, d_cls_b, size_t(num_classes) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)) {
+    set_error("fcn_head: conv_seg bias copy failed");
+    return DDP_E_LAUNCH;
+  }
+  pr.A = cur;
+  pr.out = nxt;
+  pr.stream = o.stream;
+  pr.ns = 8;
+  pr.conv_h = pr.conv_w = 0;
+  pr.bias = o.cls_bias;
+  DDP_TRY(launch_b3_sgemm(&pr, 1, 0, 0, st));
+  return launch_blk_to_row(nxt, o.logits, M, st, o.ldl, o.ldl);
 }
 
 // sampler loop around the FCN head: the head's own workspace first, then the loop's buffers

@@ -39,7 +39,6 @@ b3::Args make_b3(const unsigned short* A_sb, const SplitW& w, const float* bias,
   a.K = K;
   a.n_tiles_n = 1;
   a.acc_bias = bias;
-  a.conv_h = a.conv_w = a.conv_dil = 0;
   return a;
 }
 
@@ -69,31 +68,6 @@ int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* b
   return launch_b3<8, TAG_HEAD>(ga, e, st);
 }
 
-// 3x3 convolution (256 -> 256 channels, zero padding) as an implicit GEMM over the SB input: out (M,256) row-major =
-// act(conv + bias); weights packed tap-major (256, 9*256) and split
-int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* bias, float* out, int ldo, int maps, int h,
-                      int wd, int dilation, int act, hipStream_t st) {
-  EpiRow e;
-  e.add = nullptr;
-  e.ld_add = 0;
-  e.rn = 0;
-  e.n_tok = 0;
-  e.out = out;
-  e.ldo = ldo;
-  e.n_valid = 256;
-  e.gelu = act;
-  b3::Args ga = make_b3(X_sb, w, bias, maps * h * wd, 256, 2304);
-  ga.conv_h = h;
-  ga.conv_w = wd;
-  ga.conv_dil = dilation;
-  ga.n_tiles_n = 1;
-  constexpr size_t lds = b3::lds_bytes<8, EpiRow>();
-  static LdsAttrOnce attr;
-  attr.ensure(reinterpret_cast<const void*>(&b3::k_gemm<8, EpiRow, TAG_GENERIC, true>), int(lds));
-  if (ga.M <= 0) return DDP_OK;
-  hipLaunchKernelGGL((b3::k_gemm<8, EpiRow, TAG_GENERIC, true>), dim3(b3::grid(ga.M, 1)), dim3(b3::THREADS), lds, st, ga, e);
-  return check_launch("b3::k_gemm (conv3x3)");
-}
 
 
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
@@ -357,6 +331,7 @@ int launch_b3_sgemm(const SgemmProblem* pr, int n, int act, int conv_dil, hipStr
     g.tile0 = tiles;
     g.conv_h = pr[i].conv_h;
     g.conv_w = pr[i].conv_w;
+    g.bias = pr[i].bias;
     g.gn_partial = pr[i].gn_partial;
     g.gn_N = pr[i].gn_N;
     if (g.gn_partial && (g.gn_N < 32 || g.gn_N % 32 || pr[i].M % g.gn_N)) {

@@ -87,8 +87,6 @@ struct SplitW {
 };
 int launch_b3_linear(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                      int rn, int n_tok, float* out, int ldo, int M, int N, int K, hipStream_t st, int tag);
-int launch_b3_conv3x3(const unsigned short* X_sb, const SplitW& w, const float* bias, float* out, int ldo, int maps, int h,
-                      int wd, int dilation, int act, hipStream_t st);
 int launch_b3_linear_sb(const unsigned short* A_sb, const SplitW& w, const float* bias, const float* add, int ld_add,
                         int rn, int n_tok, unsigned short* out_sb, float* out_f32_blk, int M, int N, int K, int gelu,
                         hipStream_t st, int tag);
@@ -180,6 +178,7 @@ struct SgemmProblem {
   float* out;                   // fp32 fragment-major, 256 channels, rows padded to 128
   const unsigned char* stream;  // ns wide stage images
   int M, ns, conv_h, conv_w;    // conv_h > 0: 3x3 convolution view (ns = 72)
+  const float* bias;            // optional (256 floats)
   double* gn_partial;           // optional: fused GroupNorm partial sums [image][token / 32][32 groups][2] (gn_N % 32 == 0)
   int gn_N;                     // tokens per image
 };
@@ -209,7 +208,8 @@ int launch_msda_gather_sb(const float* value, const float* samp, unsigned short*
 // else SB
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
                               int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st);
-int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st);
+// fragment-major (256 channels) -> row-major rows of `ld` floats, the first `cols` channels (cols % 4 == 0)
+int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st, int ld = 256, int cols = 256);
 // adapters of ddp_msda_forward_lds: plain layouts -> padded map / head-major table / guess tables, SB -> row-major
 int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,
                                 float* samp_hm, float* tab_y, float* tab_x, int rows, int n_tok, int h, int w, hipStream_t st);
@@ -264,7 +264,7 @@ int launch_gn_apply_add_blk(const float* y_blk, const float* stats, const float*
 int launch_gn_apply_nchw_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, float* out, int B, int N,
                              hipStream_t st);
 int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st);
-// 3x3 convolution as an implicit GEMM (FCNHeadWithTime, FPN): weights packed tap-major, launch_b3_conv3x3
+// 3x3 convolution as an implicit GEMM (FCNHeadWithTime, FPN: launch_b3_sgemm with conv_h > 0): weights packed tap-major
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,
                     const float* conv_bias, const float* film, float* scale, float* shift, hipStream_t st);

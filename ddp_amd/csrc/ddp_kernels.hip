@@ -1670,14 +1670,14 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
   return check_launch("k_msda_gather_lds");
 }
 // fragment-major fp32 (accumulator layout, 256 channels) -> row-major: one wave per token
-__global__ void __launch_bounds__(256) k_blk_to_row(const float* __restrict__ in, float* __restrict__ out, int rows) {
+__global__ void __launch_bounds__(256) k_blk_to_row(const float* __restrict__ in, float* __restrict__ out, int rows, int ld, int cols) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= rows) return;
-  *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(in + blk_off256(m, lane * 4));
+  if (m >= rows || lane * 4 >= cols) return;
+  *reinterpret_cast<f32x4*>(out + size_t(m) * ld + lane * 4) = *reinterpret_cast<const f32x4*>(in + blk_off256(m, lane * 4));
 }
-int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st) {
-  hipLaunchKernelGGL(k_blk_to_row, dim3(cdiv(rows, 4)), dim3(256), 0, st, in_blk, out, rows);
+int launch_blk_to_row(const float* in_blk, float* out, int rows, hipStream_t st, int ld, int cols) {
+  hipLaunchKernelGGL(k_blk_to_row, dim3(cdiv(rows, 4)), dim3(256), 0, st, in_blk, out, rows, ld, cols);
   return check_launch("k_blk_to_row");
 }
 int launch_msda_lds_adapters_in(const float* value, const float* samp, const float* guess, float* vpad, size_t vpad_floats,

@@ -64,9 +64,6 @@ struct Args {
   int M, N, K;
   int n_tiles_n;
   const float* acc_bias;
-  // CONV (3x3 convolution as an implicit GEMM): A is the 256-channel SB input of (M / (h*w)) maps of h x w tokens,
-  // K = 9 * 256 with k = tap * 256 + c, tap = ky * 3 + kx, zero padding, dilation dil
-  int conv_h, conv_w, conv_dil;
 };
 
 __device__ __forceinline__ f32x16 mma(u32x4 w, u32x4 a, f32x16 c) {
@@ -110,10 +107,8 @@ __device__ __forceinline__ void store_tile_sb(const f32x16& a, unsigned short* s
   }
 }
 
-// CONV = true: the A fragment of k-tile kt is not a slice of the wave's own token group but the 32 tokens shifted by
-// the tap's (dy, dx): every lane fetches the 16-B slot of ITS source token (a rotated, at most two-group range: still
-// two contiguous segments per load), lanes whose source falls outside the map read zeros - no im2col buffer.
-template <int NT, class Epi, int TAG, bool CONV = false>
+// (3x3 convolutions run as implicit GEMMs on the persistent stream kernel: layer_bf16x3.h MODE 5)
+template <int NT, class Epi, int TAG>
 __global__ void __launch_bounds__(THREADS, 2)
 k_gemm(Args ga, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,41 +159,17 @@ k_gemm(Args ga, Epi epi) {
   };
 
   // activation fragments: SB buffer, this wave's 32-token group
-  const char* a_src = reinterpret_cast<const char*>(ga.A) + (size_t(m0 >> 5) + wave) * (CONV ? 256 : ga.K) * 192 + lane * 16;
-  // CONV: this lane's output token (b, ci, cj)
-  int cm = 0, ci = 0, cj = 0;
-  if constexpr (CONV) {
-    const int m = m0 + wave * 32 + j;
-    cm = m < M ? m : -1;
-    const int mm = m < M ? m : M - 1;
-    const int n_img = ga.conv_h * ga.conv_w;
-    const int n = mm - (mm / n_img) * n_img;
-    ci = n / ga.conv_w;
-    cj = n - ci * ga.conv_w;
-  }
+  const char* a_src = reinterpret_cast<const char*>(ga.A) + (size_t(m0 >> 5) + wave) * ga.K * 192 + lane * 16;
   struct ASrc {
-    const char* p;     // address of (K16 block 0, piece 0) of this lane's source slot
-    bool ok;
+    const char* p;     // address of (K16 block 0, piece 0) of this lane's slot
   };
   auto a_source = [&](int kt) -> ASrc {
     ASrc r;
-    if constexpr (CONV) {
-      const int tap = kt >> 3;                     // 8 k-tiles (256 channels) per tap
-      const int dy = (tap / 3 - 1) * ga.conv_dil, dx = (tap - (tap / 3) * 3 - 1) * ga.conv_dil;
-      r.ok = cm >= 0 && ci + dy >= 0 && ci + dy < ga.conv_h && cj + dx >= 0 && cj + dx < ga.conv_w;
-      const int ms = r.ok ? cm + dy * ga.conv_w + dx : 0;
-      r.p = reinterpret_cast<const char*>(ga.A) + size_t(ms >> 5) * 256 * 192 + (h * 32 + (ms & 31)) * 16 +
-            size_t((kt & 7) * 2) * 3 * 1024;
-    } else {
-      r.p = a_src + size_t(kt) * 2 * 3 * 1024;
-      r.ok = true;
-    }
+    r.p = a_src + size_t(kt) * 2 * 3 * 1024;
     return r;
   };
   auto a_frag = [&](const ASrc& sp, int ks, int comp) -> u32x4 {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (!CONV || sp.ok) v = *reinterpret_cast<const u32x4*>(sp.p + (ks * 3 + comp) * 1024);
-    return v;
+    return *reinterpret_cast<const u32x4*>(sp.p + (ks * 3 + comp) * 1024);
   };
 
   f32x16 acc[NT];

@@ -116,6 +116,7 @@ struct LayerArgs {
     const float* A;
     float* out;
     const unsigned char* stream;
+    const float* bias;       // optional (256): added before the activation
     double* gn_partial;      // optional: GroupNorm(32 groups of 8 channels) partial sums of the result, [image][token / 32][group]
                              // {sum, sum of squares} - one entry per wave; needs gn_N % 32 == 0 (a wave's 32 tokens in one image)
     int M, ns, tile0, conv_h, conv_w, gn_N;
@@ -685,10 +686,18 @@ k_layer(LayerArgs la) {
       u32x4 sc[2][3];
       f32x4 sf[4], sh[2];
       a_load(0, sf);
+      {
+        const float* bp = la.gp[pi].bias;
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+          for (int g = 0; g < 4; ++g) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (bp) b = *reinterpret_cast<const f32x4*>(bp + t * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
+          }
+      }
       u32x4 w[2][3];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
