@@ -258,7 +258,8 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
 int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, size_t* bytes);
 /* flags of the two neck entries: the workspace starts with a weight region (split weight planes as the stage images of the
  * stream GEMM) whose layout depends on the channel counts only; a caller that runs the same weights again through the same
- * workspace buffer passes DDP_NECK_WEIGHTS_READY and the weights are not re-packed. */
+ * workspace buffer - on the same stream, or after synchronising with the call that packed them - passes
+ * DDP_NECK_WEIGHTS_READY and the weights are not re-packed. */
 #define DDP_NECK_WEIGHTS_READY 1
 int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* level_w, int batch,
                  const float* d_conv_w, const float* d_gn_w, const float* d_gn_b, int align_corners, int flags, float* d_out,
