@@ -375,6 +375,34 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
       : "memory");
 }
 
+// DDP_GL_V: build-time level of the block's latency chain (same-box A/B: scripts/variant_build.sh x -DDDP_GL_V=0):
+//   0  round-3 baseline: origin guess (scalar table loads) -> sample-table loads -> fill by inline-asm LDS-DMA -> vmcnt(0) ->
+//      butterfly reduction of the mean by ds_bpermute -> barrier
+//   1  sample-table loads issued FIRST (they depend on nothing but the kernel arguments: in flight under the scalar loads of
+//      the guess), mean reduced by DPP row operations (no trip through the LDS crossbar, no lgkmcnt waits)
+// (The fill stays inline asm: __builtin_amdgcn_global_load_lds is counted by the compiler's s_waitcnt insertion as a FLAT
+// operation that touches both address spaces - "pending flat": every later wait becomes vmcnt(0) lgkmcnt(0) - so it buys no
+// finer wait than the asm form, which that pass cannot see at all.)
+#ifndef DDP_GL_V
+#define DDP_GL_V 1
+#endif
+
+// sum over the 64 lanes by DPP: quad permutes, row_half_mirror, row_mirror (every lane of a row of 16 holds the row's sum),
+// row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 - lanes 48..63 hold the total
+__device__ __forceinline__ float gl_wave_sum_hi(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) __attribute__((always_inline)) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});      // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});      // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});     // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});     // row_mirror
+  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});     // row_bcast15 -> rows 1, 3
+  v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});     // row_bcast31 -> rows 2, 3
+  return v;
+}
+
 // Each of a token's 8 lanes does the coordinate arithmetic of ONE sample point (p = q & 3) and the results travel to the
 // other lanes by ds_swizzle (a cross-lane move through the LDS crossbar, no storage) instead of every lane redoing all four
 // points (0.214 -> 0.206 ms, r02d); the 3-way split of the result happens BEFORE the quad exchange (each lane splits its
@@ -447,6 +475,18 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
     // block reduction -> origin".  The tile's actual mean is then formed from the coordinates the taps need anyway, and the
     // window is refilled only when it sits 2 px or more away from the guess (any origin is CORRECT - taps outside the window
     // take the mixed path - the mean only decides how many do).
+    // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
+    float px_[NG], py_[NG], pw_[NG];
+    auto table_loads = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float* sp = simg + size_t(mtok[g]) * 12;
+        px_[g] = sp[2 * (q & 3)];
+        py_[g] = sp[2 * (q & 3) + 1];
+        pw_[g] = sp[8 + (q & 3)];
+      }
+    };
+    if constexpr (DDP_GL_V >= 1) table_loads();
     int ox, oy;
     {
       float gx = 0.f, gy = 0.f;
@@ -465,15 +505,7 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
       oy = __builtin_amdgcn_readfirstlane(y0 + int(rintf(gy)) - GL_HALO);
     }
     {
-    // this lane's sample point p = q & 3 of its two tokens (x, y, attention weight): in flight under the window fill
-    float px_[NG], py_[NG], pw_[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const float* sp = simg + size_t(mtok[g]) * 12;
-      px_[g] = sp[2 * (q & 3)];
-      py_[g] = sp[2 * (q & 3) + 1];
-      pw_[g] = sp[8 + (q & 3)];
-    }
+    if constexpr (DDP_GL_V == 0) table_loads();
     // ---- fill: window pixel idx = py * GL_WW + px <- padded map pixel (oy + 1 + py, ox + 1 + px), clamped into the map
     auto fill = [&]() __attribute__((always_inline)) {
       for (int k = wave; k < GL_DMA; k += G::NW) {
@@ -498,14 +530,23 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
           sy += py_[g] - float(y0 + tl / GL_TW);
         }
       }
+      if constexpr (DDP_GL_V >= 1) {
+        sx = gl_wave_sum_hi(sx);
+        sy = gl_wave_sum_hi(sy);
+        if (lane == 63) {
+          msum[wave][0] = sx;
+          msum[wave][1] = sy;
+        }
+      } else {
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        sx += __shfl_xor(sx, o, 64);
-        sy += __shfl_xor(sy, o, 64);
-      }
-      if (lane == 0) {
-        msum[wave][0] = sx;
-        msum[wave][1] = sy;
+        for (int o = 1; o < 64; o <<= 1) {
+          sx += __shfl_xor(sx, o, 64);
+          sy += __shfl_xor(sy, o, 64);
+        }
+        if (lane == 0) {
+          msum[wave][0] = sx;
+          msum[wave][1] = sy;
+        }
       }
       __syncthreads();                                       // the window (guess) is complete, the partial sums are visible
       float mx = 0.f, my = 0.f;
