@@ -277,6 +277,39 @@ class PowerSampler:
                 'samples': len(ss), 'power_cap_w': self.cap_w, 'source': self.source, 'first_raw_reading': self.first_raw}
 
 
+def vendor_gemm_reference(dev, index=0, seconds=1.2, n=8192):
+    """What the vendor's own bf16 GEMM (torch.matmul -> hipBLASLt) sustains on THIS box, with power and clock beside it: the
+    layer kernel's roofline uses the nominal 2500 TFLOP/s, which the part does not deliver under its package power cap to
+    anything that keeps the matrix pipes busy (scripts/power_calibration.py).  One line of context next to
+    `roofline.frac`, measured after the timed region; never part of `value`."""
+    try:
+        a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        c = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+        torch.matmul(a, b, out=c)
+        torch.cuda.synchronize()
+        ps = PowerSampler(index)
+        ps.start()
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                torch.matmul(a, b, out=c)
+            k += 4
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ps.stop()
+        tf = k * 2.0 * n ** 3 / (t1 - t0) / 1e12
+        rec = {'kernel': f'torch.matmul bf16 {n}x{n}x{n} (hipBLASLt)', 'tflops': round(tf, 1),
+               'frac_of_bf16_peak': round(tf / BF16_MFMA_PEAK_TFLOPS, 4)}
+        pw = ps.summary(t0 + 0.3, t1) if ps.source is not None else None
+        if pw:
+            rec.update(power_w=pw['power_w'], sclk_mhz=pw['sclk_mhz'])
+        return rec
+    except Exception as e:                                   # context only: never fail the bench line over it
+        return {'error': f'{type(e).__name__}: {e}'[:160]}
+
+
 def size_stream(n_sizes, sd, wl, dev):
     """The reference's test protocol on the plugin surface: one image per call, a new (h, w) almost every call.  Returns the
     streaming rate and the cost of a geometry change relative to the loop time of the same image at a fixed geometry."""
@@ -553,6 +586,8 @@ def main():
             roofline['sclk_mhz'] = power['sclk_mhz']
         roofline['loop_tflops'] = round(loop_flops / (ms_per_step * 1e-3) / 1e12, 2)
         roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
+        if rank == 0 and not args.no_power and eng.gemm == 'bf16x3':
+            roofline['same_box_vendor_gemm'] = vendor_gemm_reference(dev, local_rank)
 
     # ---- rows either side of the loop (optional, rank 0): the neck that produces x, the epilogue that consumes out --
     next_rows = None

@@ -69,7 +69,7 @@ rows = list(out.items())
 json.dump(dict(rows), open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),
                   ('prof_next/**/*kernel_stats.csv', f'{tag}_kernel_stats_next_rows.csv'), ('bench.json', f'{tag}_bench.json'),
-                  ('pytest_gpu.txt', f'{tag}_pytest_gpu.txt')):
+                  ('pytest_gpu.txt', f'{tag}_pytest_gpu.txt'), ('power_calibration.json', f'{tag}_power_calibration.json')):
     f = glob.glob(os.path.join(src, pat), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, name))

@@ -54,8 +54,11 @@ done
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
     --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power --force-dist > $OUT/force_dist_rccl_world1.json 2> $OUT/force_dist_rccl_world1.err
 tail -1 $OUT/force_dist_rccl_world1.json | cut -c1-300
+# what this box gives the matrix pipes under its package power cap: vendor bf16 GEMM, MFMA-only loops
+[ "$QUICK" = quick ] || timeout 300 python scripts/power_calibration.py > $OUT/power_calibration.json 2> $OUT/power_calibration.err
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -30 "$f"
 python scripts/collect_profiles.py $TAG --print-only
 # quick mode: the measurements first, the tests last
 [ "$QUICK" = quick ] && run_tests
+exit 0

@@ -53,11 +53,13 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       // the fragment read here is consumed two operand rotations later
-      // asm, so that the read stays HERE (the compiler would sink it next to its use and expose the LDS latency); the counted
-      // wait leaves the newest read in flight: the operand used now was read two rotations ago
+      // asm, so that the read stays HERE (the compiler would sink it next to its use and expose the LDS latency).  The counted
+      // wait only bounds the reads in flight (a wait for the previous read - lgkmcnt(1) - stalls the wave for most of an LDS
+      // round trip every two MFMAs: 43 cycles per MFMA instead of 33, r03l); the MFMAs may consume a fragment register whose
+      // read is still in flight - stale bits, which is all a power benchmark needs
       if (LDSR && (u % 2 == 0 || LDSR == 2)) {
         const unsigned addr = lds_base + (((unsigned(it) * 16u + u) * 64u + lane) % 3072u) * 16u;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(1)" : "=v"(a[(u / CHAINS + 2) & 3]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(3)" : "=v"(a[(u / CHAINS + 2) & 3]) : "v"(addr));
       }
       acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(u / CHAINS) & 3]), __builtin_bit_cast(bf16x8, b[(u / CHAINS + u) & 3]), acc[u % CHAINS], 0, 0, 0);
 #pragma unroll
