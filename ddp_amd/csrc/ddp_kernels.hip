@@ -380,11 +380,12 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 //      butterfly reduction of the mean by ds_bpermute -> barrier
 //   1  sample-table loads issued FIRST (they depend on nothing but the kernel arguments: in flight under the scalar loads of
 //      the guess), mean reduced by DPP row operations (no trip through the LDS crossbar, no lgkmcnt waits)
+//   2  1 + a point's corner offset and weights reach the token's 8 lanes by DPP quad_perm broadcasts instead of ds_swizzle
 // (The fill stays inline asm: __builtin_amdgcn_global_load_lds is counted by the compiler's s_waitcnt insertion as a FLAT
 // operation that touches both address spaces - "pending flat": every later wait becomes vmcnt(0) lgkmcnt(0) - so it buys no
 // finer wait than the asm form, which that pass cannot see at all.)
 #ifndef DDP_GL_V
-#define DDP_GL_V 1
+#define DDP_GL_V 2
 #endif
 
 // sum over the 64 lanes by DPP: quad permutes, row_half_mirror, row_mirror (every lane of a row of 16 holds the row's sum),
@@ -607,12 +608,26 @@ __global__ void __launch_bounds__(NT, MINW) k_msda_gather_lds(const float* __res
         auto point = [&](auto ppc) __attribute__((always_inline)) {
           // fetch point pp from lane (token, pp) of this token's 8 lanes: lane' = (lane & 0x18) | pp within each 32-lane half
           // (ds_swizzle bit mode: and_mask [4:0], or_mask [9:5], xor_mask [14:10])
-          constexpr int pat = (decltype(ppc)::value << 5) | 0x18;
-          const int o = __builtin_amdgcn_ds_swizzle(aoff, pat);
-          const float a00 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w00), pat));
-          const float a01 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w01), pat));
-          const float a10 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w10), pat));
-          const float a11 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w11), pat));
+          int o;
+          float a00, a01, a10, a11;
+          if constexpr (DDP_GL_V >= 2) {
+            // lanes q and q + 4 of a token hold the SAME point (both loaded entry q & 3), so "lane (token, pp)" exists in
+            // either quad of the token's 8 lanes: a DPP quad_perm broadcast (a VALU move) instead of a trip through the
+            // LDS crossbar and its lgkmcnt wait
+            constexpr int qp = decltype(ppc)::value * 0x55;
+            o = __builtin_amdgcn_mov_dpp(aoff, qp, 0xF, 0xF, true);
+            a00 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w00), qp, 0xF, 0xF, true));
+            a01 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w01), qp, 0xF, 0xF, true));
+            a10 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w10), qp, 0xF, 0xF, true));
+            a11 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w11), qp, 0xF, 0xF, true));
+          } else {
+            constexpr int pat = (decltype(ppc)::value << 5) | 0x18;
+            o = __builtin_amdgcn_ds_swizzle(aoff, pat);
+            a00 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w00), pat));
+            a01 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w01), pat));
+            a10 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w10), pat));
+            a11 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w11), pat));
+          }
           f32x4 v00, v01, v10, v11;
           corners_lds(o, v00, v01, v10, v11);
           accumulate(v00, v01, v10, v11, a00, a01, a10, a11);
