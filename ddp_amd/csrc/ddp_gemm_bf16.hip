@@ -160,13 +160,18 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
 #ifdef DDP_LYR_STAMP
   la.stamps = g_lyr_stamps;
 #endif
-  static LdsAttrOnce attr;
+  static LdsAttrOnce attr, attr_nt;
   attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN>), int(b3::LYR_LDS_B));
+  attr_nt.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN, 0, 0, true>), int(b3::LYR_LDS_B));
   const int n_cu = cu_count();
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;       // persistent: one block per CU walks tiles blockIdx, +grid, ...
   prof_begin(TAG_FC2_LN, st);
-  hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  // activation tensors too large to survive in L2 / MALL until the next kernel reads them: non-temporal streams (layer_bf16x3.h)
+  if (a.M >= b3::LYR_NT_MIN_TOKENS)
+    hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN, 0, 0, true>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  else
+    hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
   prof_end(TAG_FC2_LN, st);
   return check_launch("b3::k_layer");
 }

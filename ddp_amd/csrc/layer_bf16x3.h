@@ -328,7 +328,27 @@ constexpr int LYR_NSTAMP = 16;
 #define DDP_LYR_STAMP_AT(i)
 #endif
 
-template <int TAG, int MODE = 0, int NCH = 0>
+// NT: the activation streams of the kernel that are touched once per launch (attention output, residual rows, q' / v' /
+// sample-table stores) carry the non-temporal hint.  Same-box A/B at C2 (profiles/r03n_ab_nontemporal_streams.txt): the
+// layer kernel itself does not care (1.490 vs 1.495 ms), but the gather that follows gets 3 % faster (0.1579 -> 0.1533 ms: v'
+// and the sample table no longer sit in L2 as dirty lines to be written back while the gather streams them in again), +0.7 %
+// on the batch.  At B = 1 (32 768 tokens) it is the other way round - v' (33 MB) and the table stay L2 / MALL resident between
+// the two kernels, the hint throws that away (gather 0.0208 -> 0.0252 ms, -3 % on the image) - hence a template parameter
+// chosen per launch by the token count (launch_b3_layer), not a build switch.  (The same hint on the GATHER's own table loads
+// and result stores costs it 1 %: not used.)
+constexpr int LYR_NT_MIN_TOKENS = 131072;                    // >= 128 MiB per fp32 activation tensor: beyond L2 + MALL reuse
+template <bool NT>
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  else return *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float* p, const f32x4& v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+
+template <int TAG, int MODE = 0, int NCH = 0, bool NT = false>
 __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -613,7 +633,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) qv[i][g] = *reinterpret_cast<const f32x4*>(qp + (half * 4 + i) * 1024 + g * 256);
+        for (int g = 0; g < 4; ++g) qv[i][g] = ld_stream<NT>(qp + (half * 4 + i) * 1024 + g * 256);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -628,8 +648,8 @@ k_layer(LayerArgs la) {
   };
   // eight values of K16 block b (as produced for split8) -> q in HBM
   auto store_q_block = [&](float* qp, int b, const float (&xv)[8]) __attribute__((always_inline)) {
-    *reinterpret_cast<f32x4*>(qp + (b >> 1) * 1024 + (2 * (b & 1)) * 256) = f32x4{xv[0], xv[1], xv[2], xv[3]};
-    *reinterpret_cast<f32x4*>(qp + (b >> 1) * 1024 + (2 * (b & 1) + 1) * 256) = f32x4{xv[4], xv[5], xv[6], xv[7]};
+    st_stream<NT>(qp + (b >> 1) * 1024 + (2 * (b & 1)) * 256, f32x4{xv[0], xv[1], xv[2], xv[3]});
+    st_stream<NT>(qp + (b >> 1) * 1024 + (2 * (b & 1) + 1) * 256, f32x4{xv[4], xv[5], xv[6], xv[7]});
   };
 
   DDP_LYR_STAMP_DECL
@@ -1046,7 +1066,7 @@ k_layer(LayerArgs la) {
     const float* sfp = la.Sf + grp * 8192 + lane * 4;
     if constexpr (SF) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) sf[g] = *reinterpret_cast<const f32x4*>(sfp + g * 256);
+      for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + g * 256);
     } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1091,7 +1111,7 @@ k_layer(LayerArgs la) {
         const int stn = st + 1;
         if constexpr (SF) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) sf[g] = *reinterpret_cast<const f32x4*>(sfp + stn * 1024 + g * 256);
+          for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + stn * 1024 + g * 256);
         } else {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
@@ -1200,13 +1220,13 @@ k_layer(LayerArgs la) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
+      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qf + t * 1024 + g * 256);
     p0_stage(6, I0, I0);
     DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
 #pragma unroll
     for (int t = 4; t < 8; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) qr[t][g] = *reinterpret_cast<const f32x4*>(qf + t * 1024 + g * 256);
+      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qf + t * 1024 + g * 256);
     p0_stage(7, I1, I0);
 
     DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages
@@ -1449,7 +1469,7 @@ k_layer(LayerArgs la) {
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]};
+              st_stream<NT>(dst + t * 32 + 8 * g, f32x4{a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]});
         }
       }
       DDP_LYR_STAMP_AT(6)                                      // next value_proj (8 stages + stores)
@@ -1500,7 +1520,7 @@ k_layer(LayerArgs la) {
               // head-major table [head][token][8 coordinates | 4 weights]: the gather runs one head per block.  This lane's four
               // columns are sc2 * 64 + t * 32 + 8g + 4h ..: coordinates of head 4t + g (points 2h, 2h + 1) / weights of head 2g + h
               const int shd = sc2 == 0 ? (t * 4 + g) : 2 * g + h;
-              *reinterpret_cast<f32x4*>(la.samp_out + (size_t(shd) * M + m) * 12 + (sc2 == 0 ? 4 * h : 8)) = v;
+              st_stream<NT>(la.samp_out + (size_t(shd) * M + m) * 12 + (sc2 == 0 ? 4 * h : 8), v);
             }
           }
         }
