@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int CHAINS, int LDSR, int VALU>
 __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc, int iters, int pattern) {
-  __shared__ u32x4 lds[LDSR ? 3072 : 1];                  // 48 KiB: one stage image of the layer kernel
+  __shared__ u32x4 lds[LDSR ? 3072 : 1];                  // 48 KiB: one stage image of the layer kernel (32 KiB of it are read)
   // operands: zeros (pattern 0: the multiplier array does not toggle) or pseudo-random bf16 bit patterns (random sign and mantissa, exponent of
   // 1.0 (pattern 1: what the split pieces of real activations look like to the datapath)
   unsigned s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
       // round trip every two MFMAs: 43 cycles per MFMA instead of 33, r03l); the MFMAs may consume a fragment register whose
       // read is still in flight - stale bits, which is all a power benchmark needs
       if (LDSR && (u % 2 == 0 || LDSR == 2)) {
-        const unsigned addr = lds_base + (((unsigned(it) * 16u + u) * 64u + lane) % 3072u) * 16u;
+        const unsigned addr = lds_base + (((unsigned(it) * 16u + u) * 64u + lane) & 2047u) * 16u     /* (a power of two: no integer division in the loop) */;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(3)" : "=v"(a[(u / CHAINS + 2) & 3]) : "v"(addr));
       }
       acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(u / CHAINS) & 3]), __builtin_bit_cast(bf16x8, b[(u / CHAINS + u) & 3]), acc[u % CHAINS], 0, 0, 0);
