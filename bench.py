@@ -402,6 +402,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when the process group comes up
+    # (seen in profiles/r03_force_dist_rccl_world1.json), rocm libraries may do the same.  Everything anybody writes to fd 1
+    # from here on goes to stderr; the line itself is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != max(args.gpus, 1):
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} '
                          f'(or run `python bench.py --gpus {args.gpus}` without a rendezvous environment)')
@@ -748,7 +754,9 @@ def main():
             'roofline': roofline, 'power': power, 'joules_per_image': (power or {}).get('joules_per_image'),
             'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows, 'size_stream': stream_res,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
+    os.close(json_fd)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
