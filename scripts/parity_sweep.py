@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""The three parity figures of tests/test_full_size_parity.py for EVERY image of a BASELINE configuration's per-GPU batch (the
+test suite checks two images of C2 and one of C3 to stay within minutes): decisions fed / free-running / reference-vs-reference
+per image, and how often `free <= max(1e-3, 2 x reference-vs-reference)` holds.  Evidence, not a test - the CPU oracle runs 3-4
+times per image.
+
+  gpurun --timeout 900 -- 'python scripts/parity_sweep.py --config c2 > gpurun_out/<tag>/parity_sweep_c2.txt'"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_full_size_parity as T  # noqa: E402
+from ddp_amd.engine import DDPEngine  # noqa: E402
+from ddp_amd.utils import synthetic  # noqa: E402
+
+CONFIGS = {   # name: (B, h, w, K, classes, layers, accumulation, oracle variants)
+    'c2': (8, 128, 256, 3, 150, 6, True, ('fp64',)),
+    'c3': (4, 256, 512, 10, 19, 6, False, ('taps',)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
+    ap.add_argument('--images', default='', help='comma-separated image indices (default: all of the batch)')
+    args = ap.parse_args()
+    B, h, w, K, ncls, L, acc, variants = CONFIGS[args.config]
+    dev = torch.device('cuda:0')
+    torch.set_num_threads(T._usable_cores())
+    sd = synthetic.make_state_dict('seg', ncls, L, 256, seed=2)
+    x, noise = synthetic.make_inputs(B, h, w, 1, 256, 256, seed=0)
+    eng = DDPEngine(sd, 'seg', h=h, w=w, batch=B, randsteps=1, timesteps=K, num_classes=ncls, bit_scale=0.01,
+                    accumulation=acc, device=dev, record_x0=True)
+    out = eng.sample(x.to(dev), noise.to(dev)).cpu()
+    images = [int(i) for i in args.images.split(',') if i] or list(range(B))
+    held = 0
+    for b in images:
+        try:
+            T._seg_parity_with_decisions(args.config.upper(), eng, out, x, noise, sd, b, K, acc, variants)
+            held += 1
+        except AssertionError as e:
+            print(f'{args.config.upper()} image {b}: ASSERTION FAILED {e}')
+        sys.stdout.flush()
+    print(f'{args.config.upper()}: the gate free <= max(1e-3, 2 x reference-vs-reference) (and decisions-fed <= 1e-3) held for {held} of {len(images)} images')
+
+
+if __name__ == '__main__':
+    main()
