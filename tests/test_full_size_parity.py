@@ -23,6 +23,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
+# The largest distance the REFERENCE restated twice was seen to end from itself, free-running, per problem size
+# (scripts/reference_drift_sweep.py, profiles/r03w_reference_drift_c3.txt: 16 pairs over 8 C3-size images, 0.65e-3 .. 2.05e-3).
+# One pair on one image is a single draw of that distance - it even depends on the oracle's thread count (the same image and pair:
+# 1.2e-5 with 16 threads, 2.05e-3 with 8; profiles/r03x_*) - so the free-running assertion accepts the engine when it is within
+# twice THIS image's draw or within the worst the reference does to itself at this size.  C2 needs no entry: free-running stays
+# inside the gate on all 8 images (profiles/r03v_parity_sweep_c2.txt).
+REFERENCE_DRIFT_SEEN = {'C3': 2.05e-3}
 BEV_SCOPES = dict(input_scope=((-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8)), output_scope=((-50, 50, 0.5), (-50, 50, 0.5)))
 
 
@@ -124,7 +131,7 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
               f'reference-vs-reference {dr["ref_vs_ref"]:.3e} ' +
               ', '.join(f'[{v}: {d["max_rel"]:.3e}, {d["pixels_above_1e-4"]} px above 1e-4, {d["decisions_differ"]} decisions differ]'
                         for v, d in dr['variants'].items()))
-        assert err_f <= max(GATE, 2 * dr['ref_vs_ref']) and agree_f >= 0.9995
+        assert err_f <= max(GATE, 2 * dr['ref_vs_ref'], REFERENCE_DRIFT_SEEN.get(name, 0.0)) and agree_f >= 0.9995
     return err
 
 
