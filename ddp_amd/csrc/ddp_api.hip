@@ -1295,6 +1295,30 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
                                     static_cast<hipStream_t>(stream));
 }
 
+int ddp_depth_postprocess(const ddp_depth_aug* augs, int n_aug, int batch, int out_h, int out_w, int align_corners,
+                          float min_depth, float max_depth, float* d_out, void* stream) {
+  if (!augs) {
+    set_error("depth_postprocess: augs is NULL");
+    return DDP_E_NULL;
+  }
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (n_aug < 1 || n_aug > DDP_MAX_AUGS || batch < 1 || out_h < 1 || out_w < 1 || !(min_depth <= max_depth)) {
+    set_error("depth_postprocess: bad arguments (n_aug %d B %d out %dx%d depth range [%g, %g])", n_aug, batch, out_h, out_w,
+              double(min_depth), double(max_depth));
+    return DDP_E_BADCFG;
+  }
+  for (int i = 0; i < n_aug; ++i) {
+    const ddp_depth_aug& g = augs[i];
+    DDP_TRY(check_ptr(g.d_depth, "aug depth"));
+    if (g.h < 1 || g.w < 1 || g.flip < 0 || g.flip > 2) {
+      set_error("depth_postprocess: augmentation %d: bad geometry (map %dx%d flip %d)", i, g.h, g.w, g.flip);
+      return DDP_E_BADCFG;
+    }
+  }
+  return launch_depth_aug_postprocess(augs, n_aug, batch, out_h, out_w, align_corners ? 1 : 0, min_depth, max_depth, d_out,
+                                      static_cast<hipStream_t>(stream));
+}
+
 namespace {
 struct MsmLayout {
   // weight region first (independent of batch and map sizes: DDP_NECK_WEIGHTS_READY)

@@ -254,6 +254,8 @@ struct SegPostArgs {
 int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
 int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K, int oh, int ow, int align, unsigned char* seg,
                                float* prob, hipStream_t st);
+int launch_depth_aug_postprocess(const ddp_depth_aug* augs, int n_aug, int B, int oh, int ow, int align, float lo, float hi,
+                                 float* out, hipStream_t st);
 // necks on fp32 fragment-major ("blk") activations - the stream GEMM's operand / result layout
 int launch_nchw_to_blk(const float* in, float* out_blk, int R, int C, int N, hipStream_t st);
 int launch_gn_stats_blk(const float* y_blk, double* partial, float* stats, int B, int N, float eps, hipStream_t st);

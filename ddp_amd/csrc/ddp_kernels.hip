@@ -1004,6 +1004,58 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Post-loop epilogue of the depth toolbox, fused (depth/depth/models/depther/ddp.py:95-109 encode_decode: clamp + resize;
+// encoder_decoder.py:187-194 inference: flip; :210-229 aug_test: running sum in list order, / n).  HBM-bound: the low-resolution
+// maps (<= 107 KB per image at KITTI size) stay in L2, the only real traffic is the (B,1,H,W) store, so a thread owns 4
+// x-adjacent output pixels and writes them as one 16-B store when the row allows it.  torch.clamp keeps NaN (comparisons,
+// not fmin / fmax); the clamp comes BEFORE the interpolation, as in the reference.
+// ------------------------------------------------------------------------------------------------
+struct DepthAugArgs {
+  ddp_depth_aug aug[DDP_MAX_AUGS];
+  int n_aug, B, oh, ow, align;
+  float lo, hi;
+  float* out;
+};
+__device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__global__ void __launch_bounds__(256) k_depth_aug_postprocess(DepthAugArgs a) {
+  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x0 >= a.ow || y >= a.oh) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < a.n_aug; ++i) {
+    const ddp_depth_aug& g = a.aug[i];
+    const float* plane = g.d_depth + size_t(b) * g.h * g.w;
+    const int sy = g.flip == 2 ? a.oh - 1 - y : y;
+    const UpIdx Y = up_index(sy, g.h, a.oh, a.align);
+    const float* r0 = plane + size_t(Y.i0) * g.w;
+    const float* r1 = plane + size_t(Y.i1) * g.w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int x = min(x0 + q, a.ow - 1);
+      const int sx = g.flip == 1 ? a.ow - 1 - x : x;
+      const UpIdx X = up_index(sx, g.w, a.ow, a.align);
+      const float v = bilerp(clamp_keep_nan(r0[X.i0], a.lo, a.hi), clamp_keep_nan(r0[X.i1], a.lo, a.hi),
+                             clamp_keep_nan(r1[X.i0], a.lo, a.hi), clamp_keep_nan(r1[X.i1], a.lo, a.hi), Y, X);
+      acc[q] = i == 0 ? v : __fadd_rn(acc[q], v);
+    }
+  }
+  if (a.n_aug > 1) {
+    const float nf = float(a.n_aug);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = acc[q] / nf;
+  }
+  float* o = a.out + (size_t(b) * a.oh + y) * a.ow + x0;
+  if ((a.ow & 3) == 0) {
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (x0 + q < a.ow) o[q] = acc[q];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm of the necks: deterministic two-stage statistics (fp64, fixed order) + normalise.  The stream GEMM
 // writes the partial sums itself when it can (k_gn_final32); these kernels cover the other cases and the merged map.
 // ------------------------------------------------------------------------------------------------
@@ -1704,10 +1756,26 @@ int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K,
   a.seg = seg;
   a.prob = prob;
   const int lds = 2 * K * 64 * int(sizeof(float));
+  // the attribute is set once per device: ask for the largest size the API accepts (K = 256: 128 KiB), not this call's
   static LdsAttrOnce attr;
-  attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), lds);
+  attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), 2 * 256 * 64 * int(sizeof(float)));
   hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
   return check_launch("k_seg_aug_postprocess");
+}
+int launch_depth_aug_postprocess(const ddp_depth_aug* augs, int n_aug, int B, int oh, int ow, int align, float lo, float hi,
+                                 float* out, hipStream_t st) {
+  DepthAugArgs a;
+  for (int i = 0; i < n_aug; ++i) a.aug[i] = augs[i];
+  a.n_aug = n_aug;
+  a.B = B;
+  a.oh = oh;
+  a.ow = ow;
+  a.align = align;
+  a.lo = lo;
+  a.hi = hi;
+  a.out = out;
+  hipLaunchKernelGGL(k_depth_aug_postprocess, dim3(cdiv(ow, 256), cdiv(oh, 4), B), dim3(256), 0, st, a);
+  return check_launch("k_depth_aug_postprocess");
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
                               int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {

@@ -1,9 +1,11 @@
 """Drop-in depth ``DDP`` + ``DeformableHeadWithTime`` (depth/depth/models/depther/ddp.py:34-247;
 depth/depth/models/decode_heads/deformable_head_with_time.py:20-169): ``down`` concat-conv over
-256+1 channels, raw-t time embedding, 3x3 ``conv_depth`` regression head, cosine-gamma DDIM step."""
+256+1 channels, raw-t time embedding, 3x3 ``conv_depth`` regression head, cosine-gamma DDIM step - and the toolbox's test
+entry around it (depther/base.py:50-115 ``forward`` / ``forward_test``; encoder_decoder.py:130-235 ``whole_inference`` /
+``inference`` / ``simple_test`` / ``aug_test``), so that ``depth/tools/test.py`` runs unchanged: ``model(return_loss=False,
+**data)`` (depth/depth/apis/test.py:88,204).  Everything after the loop is ONE kernel (``ddp_depth_postprocess``)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..decode_heads.deformable_head_with_time import DeformableHeadWithTime as _SegHead
 from ..registry import DEPTHER, HEADS, build_backbone, build_head
@@ -92,14 +94,119 @@ class DDP(nn.Module, _SamplerMixin):
     def _decode_head_forward_test(self, x, t, img_metas=None):
         return self.decode_head.forward_test(x, t, img_metas, self.test_cfg)
 
+    # -- the toolbox's test entry (depth/depth/models/depther/base.py:50-115, encoder_decoder.py:130-235) ----------------
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    @property
+    def with_decode_head(self):
+        return self.decode_head is not None
+
+    @property
+    def with_auxiliary_head(self):
+        return False                     # training-only deep supervision: out of scope
+
+    def _check_mode(self):
+        """encoder_decoder.py:183-187: ``test_cfg.mode`` in ('slide', 'whole'); 'slide' is NotImplementedError there too."""
+        cfg = self.test_cfg
+        mode = (cfg.get('mode') if isinstance(cfg, dict) else getattr(cfg, 'mode', None)) if cfg is not None else None
+        if mode not in (None, 'whole', 'slide'):
+            raise AssertionError(f"test_cfg.mode must be 'slide' or 'whole', got {mode!r}")
+        if mode == 'slide':
+            raise NotImplementedError("test_cfg.mode='slide' (the reference raises here as well: encoder_decoder.py:186-187)")
+
+    def _low_res(self, img, img_metas):
+        """backbone + neck + the K-step loop: the (b,1,h/4,w/4) map every epilogue below starts from."""
+        return self.sample(self.extract_feat(img)[0], img_metas)
+
+    def _post(self, maps, flips, size):
+        from ..engine import depth_postprocess
+        return depth_postprocess(maps, flips, size, self.decode_head.min_depth, self.decode_head.max_depth, self.align_corners)
+
     def encode_decode(self, img, img_metas=None, rescale=False):
-        """depther/ddp.py:95-109."""
-        x = self.extract_feat(img)[0]
-        out = self.sample(x, img_metas)
-        out = torch.clamp(out, min=self.decode_head.min_depth, max=self.decode_head.max_depth)
-        if rescale:
-            out = F.interpolate(out, size=img.shape[2:], mode='bilinear', align_corners=self.align_corners)
-        return out
+        """depther/ddp.py:95-109: clamp to the head's depth range, resize to the network input when ``rescale`` - one fused
+        kernel (``ddp_depth_postprocess``), no intermediate (b,1,h,w) clamp result."""
+        d = self._low_res(img, img_metas)
+        return self._post([d], [None], img.shape[2:] if rescale else d.shape[2:])
+
+    def whole_inference(self, img, img_meta, rescale):
+        """encoder_decoder.py:160-166."""
+        return self.encode_decode(img, img_meta, rescale)
+
+    @staticmethod
+    def _flip_of(img_meta):
+        if img_meta and img_meta[0].get('flip', False):
+            direction = img_meta[0].get('flip_direction', 'horizontal')
+            assert direction in ('horizontal', 'vertical')
+            return direction
+        return None
+
+    def inference(self, img, img_meta, rescale):
+        """encoder_decoder.py:168-196 (mode 'whole'): ``whole_inference`` with the test-time flip undone, the flip folded into
+        the same kernel (it reads the mirrored source pixel)."""
+        self._check_mode()
+        if img_meta:
+            ori_shape = img_meta[0]['ori_shape']
+            assert all(m['ori_shape'] == ori_shape for m in img_meta)
+        d = self._low_res(img, img_meta)
+        return self._post([d], [self._flip_of(img_meta)], img.shape[2:] if rescale else d.shape[2:])
+
+    def simple_test(self, img, img_meta, rescale=True):
+        """encoder_decoder.py:198-209: list (batch) of (1,H,W) float32 arrays.  ``img`` may hold b >= 1 images (independent
+        noise per image; the reference's sampler is b = 1 only, depther/ddp.py:232)."""
+        return list(self.inference(img, img_meta, rescale).cpu().numpy())
+
+    def aug_test(self, imgs, img_metas, rescale=True):
+        """encoder_decoder.py:210-229: mean over the augmentations (KITTI / NYU test pipelines: plain + horizontal flip,
+        depth/configs/_base_/datasets/kitti.py:30-33).  Every augmentation runs the full sampling loop with its own noise; only the
+        LOW-RESOLUTION maps are kept and ONE kernel does clamp -> resize -> flip-undo -> running sum -> / n per output pixel."""
+        assert rescale, 'aug_test rescales every augmentation back to the network input'
+        self._check_mode()
+        sizes = {tuple(img.shape[2:]) for img in imgs}
+        if len(sizes) != 1:
+            # the reference adds the per-augmentation maps in place (:222-224): they must have one size
+            raise RuntimeError(f'aug_test: augmentations of different input sizes {sorted(sizes)} cannot be averaged')
+        maps, flips = [], []
+        for img, meta in zip(imgs, img_metas):
+            if meta:
+                ori_shape = meta[0]['ori_shape']
+                assert all(m['ori_shape'] == ori_shape for m in meta)
+            maps.append(self._low_res(img, meta))
+            flips.append(self._flip_of(meta))
+        return list(self._post(maps, flips, imgs[0].shape[2:]).cpu().numpy())
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:62-92: the outer lists are the test-time augmentations."""
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        for img_meta in img_metas:
+            for key in ('ori_shape', 'img_shape', 'pad_shape'):
+                vals = [m[key] for m in img_meta if key in m]
+                assert all(v == vals[0] for v in vals), f'{key} differs inside one augmentation batch'
+        if len(imgs) == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        return self.aug_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """base.py:94-108; what the harness calls: ``model(return_loss=False, **data)`` (depth/depth/apis/test.py:88,204)."""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_dummy(self, img):
+        """encoder_decoder.py:124-128."""
+        return self.encode_decode(img, None)
+
+    def val_step(self, data_batch, **kwargs):
+        """base.py:150-158."""
+        return self(**data_batch, **kwargs)
 
     def forward_train(self, *a, **k):
+        raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')
+
+    def train_step(self, *a, **k):
         raise NotImplementedError('training is out of scope of ddp_amd (SURVEY.md §8)')

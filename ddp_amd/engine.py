@@ -382,6 +382,37 @@ def seg_aug_postprocess(scores_list, metas, out_size, align_corners=False, retur
     return (seg, prob) if return_prob else seg
 
 
+def depth_postprocess(depth_list, flips, out_size, min_depth, max_depth, align_corners=False, out=None):
+    """Fused post-loop epilogue of the depth toolbox (``ddp_depth_postprocess``): (B,1,out_h,out_w) fp32 from the low-resolution
+    maps of every augmentation.  Replaces clamp -> bilinear resize (depth/depth/models/depther/ddp.py:95-109), the flip-undo of
+    ``inference`` (encoder_decoder.py:187-194) and the running mean of ``aug_test`` (:210-229).  ``depth_list[i]`` (B,1,h_i,w_i)
+    = the sampler's output for augmentation i; ``flips[i]`` None | 'horizontal' | 'vertical'.  One augmentation = ``simple_test``.
+    CUDA tensors only; no CPU path."""
+    if not depth_list or len(depth_list) != len(flips) or len(depth_list) > _lib.MAX_AUGS:
+        raise ValueError(f'depth_postprocess: 1..{_lib.MAX_AUGS} augmentations with one flip entry each')
+    if not depth_list[0].is_cuda:
+        raise _lib.DdpError('depth_postprocess: depth maps must be CUDA tensors (no CPU path)')
+    dev, B = depth_list[0].device, depth_list[0].shape[0]
+    keep = []
+    augs = (_lib.DdpDepthAug * len(depth_list))()
+    for i, (d, fl) in enumerate(zip(depth_list, flips)):
+        d = d.contiguous().float()
+        if d.dim() != 4 or d.shape[1] != 1 or d.shape[0] != B or d.device != dev:
+            raise ValueError('depth_postprocess: every augmentation needs a (B,1,h,w) map on the same device')
+        keep.append(d)
+        augs[i].d_depth = d.data_ptr()
+        augs[i].h, augs[i].w = d.shape[2], d.shape[3]
+        augs[i].flip = {None: 0, False: 0, 'horizontal': 1, 'vertical': 2}[fl]
+    oh, ow = int(out_size[0]), int(out_size[1])
+    if out is None:
+        out = torch.empty((B, 1, oh, ow), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ddp_depth_postprocess(augs, len(keep), B, oh, ow, int(bool(align_corners)), C.c_float(min_depth),
+                                             C.c_float(max_depth), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), lib)
+    return out
+
+
 def msda_forward_lds(value, samp, h, w, guess=None):
     """The deformable-attention core computed by the kernel the sampling loop runs (``ddp_msda_forward_lds``):
     value (R, h*w, 256), samp (R*h*w, 96) as for ``ddp_msda_forward``; guess (8,2) optional per-head window guess."""

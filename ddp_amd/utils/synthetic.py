@@ -156,6 +156,16 @@ def make_scores(batch, num_classes, h, w, seed):
     return torch.randn((batch, num_classes, h, w), generator=g) * 3.0
 
 
+def make_depth_map(batch, h, w, seed):
+    """Seeded low-resolution metric depth (B,1,h,w) for the depth epilogue tests: smooth + noise, with a share of the values
+    outside [1e-3, 80] on both sides so the clamp of encode_decode (depth/depth/models/depther/ddp.py:101) does something."""
+    g = torch.Generator().manual_seed(15_000 + seed)
+    yy = torch.linspace(0, 1, h).view(1, 1, h, 1)
+    xx = torch.linspace(0, 1, w).view(1, 1, 1, w)
+    base = -10.0 + 105.0 * (0.5 * xx + 0.5 * yy)            # -10 .. 95: ~10 % below min_depth, ~14 % above 80
+    return base + 6.0 * torch.randn((batch, 1, h, w), generator=g)
+
+
 def make_neck_state_dict(seed):
     """MultiStageMerging parameters with the reference's key names (necks/multi_stage_merging.py:28-37)."""
     g = torch.Generator().manual_seed(20_000 + seed)

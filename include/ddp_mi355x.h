@@ -39,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define DDP_ABI_VERSION 4
+#define DDP_ABI_VERSION 5
 #define DDP_MAX_LAYERS 12
 #define DDP_MAX_STEPS 64
 #define DDP_EMBED 256
@@ -249,6 +249,20 @@ typedef struct ddp_seg_aug {
 } ddp_seg_aug;
 int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int num_classes, int out_h, int out_w,
                             int align_corners, unsigned char* d_seg, float* d_prob, void* stream);
+
+/* Post-loop epilogue of the depth toolbox, fused (depth/depth/models/depther/ddp.py:95-109 `encode_decode`: clamp to
+ * [min_depth, max_depth], bilinear resize to the network input; encoder_decoder.py:187-194 `inference`: flip undone;
+ * :198-209 `simple_test`; :210-229 `aug_test`: running sum over the augmentations in list order, / n).  One thread per 4
+ * output pixels walks all augmentations: neither the per-augmentation (B,1,H,W) maps nor the running sum are materialised.
+ * With n_aug == 1 this is `simple_test` / `inference` / `encode_decode(rescale=True)` (x / 1 is exact); out == map size:
+ * no resize (`rescale=False`).  d_out (B,1,out_h,out_w) fp32. */
+typedef struct ddp_depth_aug {
+  const float* d_depth;    /* (B,1,h,w): ddp_sample's output (task depth) for this augmentation */
+  int32_t h, w;            /* its map size */
+  int32_t flip;            /* 0 none, 1 horizontal, 2 vertical: undone on the resized map */
+} ddp_depth_aug;
+int ddp_depth_postprocess(const ddp_depth_aug* augs, int n_aug, int batch, int out_h, int out_w, int align_corners,
+                          float min_depth, float max_depth, float* d_out, void* stream);
 
 /* MultiStageMerging neck (necks/multi_stage_merging.py:40-52): the step that produces the frozen
  * feature x of the sampling loop from the four FPN levels: bilinear resize of every level to level 0's grid, concat

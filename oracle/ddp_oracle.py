@@ -517,6 +517,27 @@ def seg_aug_test(scores_list, metas, out_size, align_corners=False):
     return acc.argmax(dim=1), acc
 
 
+def depth_postprocess(depth_list, flips, out_size, min_depth, max_depth, align_corners=False):
+    """Post-loop epilogue of the depth toolbox, the reference's own op sequence: per augmentation ``encode_decode``
+    (depth/depth/models/depther/ddp.py:95-109: clamp to the head's depth range, resize to the network input) and the flip-undo
+    of ``inference`` (depth/depth/models/depther/encoder_decoder.py:187-194); then ``aug_test`` (:210-229): in-place running
+    sum in list order, ``/= n`` - or, for ONE augmentation, ``simple_test`` (:198-209), which does not divide.
+    depth_list[i] (B,1,h_i,w_i) = the sampler's output; flips[i] None | 'horizontal' | 'vertical' -> (B,1,out_h,out_w)."""
+    acc = None
+    for d, fl in zip(depth_list, flips):
+        o = torch.clamp(d, min=min_depth, max=max_depth)
+        if tuple(o.shape[2:]) != tuple(out_size):
+            o = F.interpolate(o, size=tuple(out_size), mode='bilinear', align_corners=align_corners)
+        if fl == 'horizontal':
+            o = o.flip(dims=(3,))
+        elif fl == 'vertical':
+            o = o.flip(dims=(2,))
+        acc = o.clone() if acc is None else acc + o
+    if len(depth_list) > 1:
+        acc = acc / len(depth_list)
+    return acc
+
+
 def neck_multi_stage_merging(levels, sd, align_corners=False, prefix=''):
     """MultiStageMerging.forward (necks/multi_stage_merging.py:40-52): resize every level to level 0's grid, concat,
     down = ConvModule(1024,256,1, bias=False, GN(32), no act) (mmcv ConvModule order conv -> norm)."""

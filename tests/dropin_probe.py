@@ -11,7 +11,13 @@ Steps: (1) build the shipped config with the reference's ``build_segmentor`` / `
 (2) ``ddp_amd.register_into_mmseg()``; (3) build the SAME config with the SAME reference builder again
 (segmentation/mmseg/models/builder.py:38-49) -> must now resolve to ddp_amd's classes for the segmentor, the decode head and
 the necks, while the frozen backbone stays the reference's; (4) the state_dict key -> shape maps of everything except the
-training-only auxiliary head must be equal, and the reference's weights must load with strict=True.
+training-only auxiliary head must be equal, and the reference's weights must load with strict=True; (5) the model is CALLED the
+way the toolbox's harness calls it - ``model(return_loss=False, **data)`` with the nested augmentation lists the test
+pipeline + collate produce (segmentation/mmseg/apis/test.py:87-89, depth/depth/apis/test.py:88,204; KITTI: two augmentations,
+plain + flipped, depth/configs/_base_/datasets/kitti.py:30-33).  On this CPU-only container the call must travel through
+``forward`` -> ``forward_test`` -> ``simple_test`` / ``aug_test`` -> ... and end in ddp_amd's explicit "no CPU path" error
+- first at the neck (the reference backbone does run on the CPU), then, with the feature map handed in, inside the sampler
+(``ddim_sample`` / ``sample``) - never in ``nn.Module._forward_unimplemented`` or an AttributeError.
 Prints one JSON line.
 """
 import json
@@ -26,6 +32,44 @@ sys.path.insert(0, os.path.join(HERE, 'golden'))
 
 def shapes(model, skip=('auxiliary_head.',)):
     return {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith(skip)}
+
+
+def call_like_the_harness(model, task):
+    """(5) of the module docstring -> {'as_built': [...frames...], 'feature_given': [...frames...]}."""
+    import traceback
+
+    import torch
+    model.eval()
+    H, W = 64, 96
+    meta = dict(filename='a.png', ori_filename='a.png', ori_shape=(H, W, 3), img_shape=(H, W, 3), pad_shape=(H, W, 3),
+                scale_factor=1.0, flip=False, flip_direction='horizontal',
+                img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
+    n_aug = 2 if task == 'depth' else 1                     # KITTI: flip=True in MultiScaleFlipAug; ADE: single scale, no flip
+    data = dict(img=[torch.zeros(1, 3, H, W) for _ in range(n_aug)],
+                img_metas=[[dict(meta, flip=bool(i))] for i in range(n_aug)])
+    sampler = 'sample' if task == 'depth' else 'ddim_sample'
+    entry = ('forward', 'forward_test', 'aug_test') if task == 'depth' else ('forward', 'simple_test')
+
+    def frames_of_call():
+        try:
+            with torch.no_grad():
+                model(return_loss=False, **data)
+        except Exception as e:                              # noqa: BLE001 - the probe reports what was raised
+            names = [f.name for f in traceback.extract_tb(e.__traceback__)]
+            assert 'no CPU path' in str(e), f'{type(e).__name__}: {e}  via {names}'
+            assert '_forward_unimplemented' not in names, names
+            for fn in entry:
+                assert fn in names, (fn, names)
+            return names
+        raise AssertionError('the call returned on a CPU-only host: some CPU fallback ran')
+
+    as_built = frames_of_call()                             # reference backbone on the CPU -> ddp_amd neck refuses
+    assert 'extract_feat' in as_built, as_built
+    model.extract_feat = lambda img: [torch.zeros(img.shape[0], 256, H // 4, W // 4)]
+    given = frames_of_call()                                # feature handed in -> the sampler itself refuses
+    assert given[-1] in (sampler, '_check_feature'), given
+    assert sampler in given, given
+    return dict(as_built=as_built[-4:], feature_given=given[-4:])
 
 
 def main(task):
@@ -73,10 +117,12 @@ def main(task):
     assert not only_ref and not only_ours and not differ, dict(only_ref=only_ref[:8], only_ours=only_ours[:8], differ=differ[:8])
     res = ours.load_state_dict({k: v for k, v in ref.state_dict().items() if not k.startswith('auxiliary_head.')}, strict=True)
     hot = [k for k in b if not k.startswith(('backbone.', 'neck.'))]
+    called = call_like_the_harness(ours, task)
     print(json.dumps(dict(task=task, touched=touched, segmentor=f'{mod(ours)}.{type(ours).__name__}',
                           head=f'{mod(ours.decode_head)}.{type(ours.decode_head).__name__}', necks=necks,
                           backbone=f'{mod(ours.backbone)}.{type(ours.backbone).__name__}', keys=len(b), hot_path_keys=len(hot),
-                          hot_path_params=int(sum(ours.state_dict()[k].numel() for k in hot)), strict_load=str(res))))
+                          hot_path_params=int(sum(ours.state_dict()[k].numel() for k in hot)), strict_load=str(res),
+                          called=called)))
 
 
 if __name__ == '__main__':

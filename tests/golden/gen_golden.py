@@ -375,6 +375,62 @@ def gen_aug():
                   scores_fp=np.stack([fingerprint(t) for t in scores])))
 
 
+DPOST_CASES = [
+    # KITTI test pipeline (depth/configs/_base_/datasets/kitti.py:26-41): 352 x 1216 after KBCrop, plain + horizontal flip
+    dict(name='dpost_kitti_flip', batch=1, img=(352, 1216), align_corners=False, rescale=True, min_depth=1e-3, max_depth=80.0, seed=0,
+         augs=[dict(h=88, w=304, flip=None), dict(h=88, w=304, flip='horizontal')]),
+    # one augmentation = simple_test; odd map, input not 4x the map (Swin pads), horizontal flip
+    dict(name='dpost_simple_hflip', batch=1, img=(53, 70), align_corners=False, rescale=True, min_depth=1e-3, max_depth=80.0, seed=1,
+         augs=[dict(h=13, w=17, flip='horizontal')]),
+    # vertical flip, align_corners=True, three augmentations, maps of different sizes, NYU depth range
+    dict(name='dpost_vflip_ac3', batch=1, img=(41, 47), align_corners=True, rescale=True, min_depth=1e-3, max_depth=10.0, seed=2,
+         augs=[dict(h=11, w=12, flip=None), dict(h=11, w=12, flip='vertical'), dict(h=9, w=15, flip='horizontal')]),
+    # rescale=False: clamp + flip at the map's own size
+    dict(name='dpost_norescale', batch=1, img=(36, 44), align_corners=False, rescale=False, min_depth=1e-3, max_depth=80.0, seed=3,
+         augs=[dict(h=9, w=11, flip='horizontal')]),
+]
+
+
+def gen_dpost():
+    """Depth toolbox test entry (SURVEY.md §8 b, depth line) through the reference's OWN call chain: ``model(return_loss=False,
+    img=[...], img_metas=[[...]])`` (depth/depth/apis/test.py:88) -> base.py ``forward`` -> ``forward_test`` -> ``simple_test`` /
+    ``aug_test`` -> ``inference`` -> ``whole_inference`` -> ``DDP.encode_decode`` (clamp + resize); the backbone and the sampler
+    are replaced by seeded low-resolution maps."""
+    import ref_shim
+    build_depther, Config = ref_shim.import_depth()
+    from mmcv.cnn.utils import revert_sync_batchnorm
+    cfg_path = os.path.join(ref_shim.REF, 'depth/configs/ddp_kitti/ddp_swint_1k_w7_kitti_bs2x8_scale01.py')
+    for case in DPOST_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.min_depth = m.decode_head.min_depth = case['min_depth']
+        m.max_depth = m.decode_head.max_depth = case['max_depth']
+        model = revert_sync_batchnorm(build_depther(m)).eval()
+        model.align_corners = case['align_corners']
+        maps = [synthetic.make_depth_map(case['batch'], a['h'], a['w'], case['seed'] * 100 + i) for i, a in enumerate(case['augs'])]
+        calls = []
+        model.extract_feat = lambda img: [None]
+
+        def sample(x, img_metas, _calls=calls, _maps=maps):
+            _calls.append(1)
+            return _maps[(len(_calls) - 1) % len(_maps)].clone()
+        model.sample = sample
+        H, W = case['img']
+        imgs = [torch.zeros((case['batch'], 3, H, W)) for _ in case['augs']]
+        metas = [[dict(img_shape=(H, W, 3), ori_shape=(H, W, 3), pad_shape=(H, W, 3), flip=a['flip'] is not None,
+                       flip_direction=a['flip'] or 'horizontal')] * case['batch'] for a in case['augs']]
+        if case['rescale']:
+            res = model(return_loss=False, img=imgs, img_metas=metas)               # what apis/test.py calls
+        else:
+            res = model(return_loss=False, img=imgs, img_metas=metas, rescale=False)
+        assert isinstance(res, list) and len(res) == case['batch'] and len(calls) == len(case['augs'])
+        out = torch.from_numpy(np.stack(res))                                       # (B,1,H,W)
+        save(case['name'], dict(task='dpost', **case),
+             dict(out=out, maps_fp=np.stack([fingerprint(t) for t in maps])))
+
+
 NECK_CASES = [
     dict(name='neck_msm_even', batch=2, h=16, w=24, align_corners=False, seed=0),
     dict(name='neck_msm_odd', batch=1, h=13, w=19, align_corners=False, seed=1),
@@ -564,16 +620,16 @@ def gen_loopfcn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
         {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn,
-         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug}[args.task]()
+         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug, 'dpost': gen_dpost}[args.task]()
 
 
 if __name__ == '__main__':

@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -70,6 +70,16 @@ def load_aug_case(name):
     assert np.allclose(np.array([fingerprint(t) for t in scores]), z['scores_fp'], rtol=1e-12)
     metas = [dict(img_size=tuple(a['img']), crop_size=tuple(a['img_shape']), flip=a['flip']) for a in cfg['augs']]
     return cfg, scores, metas, torch.from_numpy(z['seg']), torch.from_numpy(z['prob']), torch.from_numpy(z['margin'])
+
+
+def load_dpost_case(name):
+    """Depth epilogue fixture (reference ``simple_test`` / ``aug_test`` / ``model(return_loss=False, **data)`` of the depth
+    toolbox): -> (cfg, [depth_i (B,1,h,w)], flips, out (B,1,H,W))."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    maps = [synthetic.make_depth_map(cfg['batch'], a['h'], a['w'], cfg['seed'] * 100 + i) for i, a in enumerate(cfg['augs'])]
+    assert np.allclose(np.array([fingerprint(t) for t in maps]), z['maps_fp'], rtol=1e-12)
+    return cfg, maps, [a['flip'] for a in cfg['augs']], torch.from_numpy(z['out'])
 
 
 def load_neck_case(name):

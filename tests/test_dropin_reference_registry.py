@@ -3,7 +3,9 @@
 Runs ``tests/dropin_probe.py`` in a subprocess (the reference import mutates sys.modules / the mmcv registries):
 ``register_into_mmseg()`` + the reference's ``build_segmentor`` / ``build_depther`` on two shipped configs must resolve to
 ddp_amd's segmentor / head / neck classes, keep the reference's backbone, and expose a state_dict whose key -> shape map
-equals the reference model's (strict load both ways).  CPU only; skipped where /root/reference is absent (GPU box).
+equals the reference model's (strict load both ways), and the built model must be CALLABLE the way the toolboxes' test
+harnesses call it (``model(return_loss=False, **data)``): on this GPU-less host the call has to end in ddp_amd's explicit
+"no CPU path" error inside the sampler, not in ``_forward_unimplemented``.  CPU only; skipped where /root/reference is absent (GPU box).
 """
 import json
 import os
@@ -34,6 +36,8 @@ def test_ade_config_builds_to_ddp_amd_classes_in_mmseg_registry():
     assert d['backbone'].startswith('mmseg.models.backbones.')          # frozen backbone stays the host toolbox's
     assert d['hot_path_params'] == 8522462                              # SURVEY.md §8b probe of the reference model
     assert 'All keys matched' in d['strict_load']
+    # the harness call model(return_loss=False, **data) reaches the sampler (and stops there: this host has no GPU)
+    assert 'simple_test' in d['called']['feature_given'] and 'ddim_sample' in d['called']['feature_given']
 
 
 def test_kitti_config_builds_to_ddp_amd_classes_in_depth_registry():
@@ -43,3 +47,5 @@ def test_kitti_config_builds_to_ddp_amd_classes_in_depth_registry():
     assert d['head'] == 'ddp_amd.depther.ddp.DepthDeformableHeadWithTime'
     assert d['backbone'].startswith('depth.models.backbones.')
     assert 'All keys matched' in d['strict_load']
+    # KITTI's two-augmentation harness call (depth/depth/apis/test.py:88) goes forward -> forward_test -> aug_test -> sample
+    assert 'aug_test' in d['called']['feature_given'] and d['called']['feature_given'][-1] == 'sample'

@@ -358,6 +358,57 @@ def test_aug_epilogue_full_size_and_errors():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('dpost'))
+def test_depth_epilogue_golden(name):
+    """fused depth epilogue (ddp_depth_postprocess) vs the reference's own ``model(return_loss=False, **data)`` output
+    (depth/depth/apis/test.py:88 -> base.py forward_test -> simple_test / aug_test): clamp, bilinear resize, flip-undo, mean."""
+    from golden_util import load_dpost_case
+    from ddp_amd.engine import depth_postprocess
+    cfg, maps, flips, out = load_dpost_case(name)
+    size = cfg['img'] if cfg['rescale'] else (cfg['augs'][0]['h'], cfg['augs'][0]['w'])
+    got = depth_postprocess([m.cuda() for m in maps], flips, size, cfg['min_depth'], cfg['max_depth'], cfg['align_corners'])
+    torch.cuda.synchronize()
+    assert got.shape == out.shape
+    err = float((got.cpu() - out).abs().max())
+    print(f'DEPTH EPILOGUE {name}: max abs diff {err:.3e} on a depth scale of {cfg["max_depth"]:g}')
+    assert err <= 2e-5 * cfg['max_depth']                     # the CPU interpolation kernel may contract to FMA
+    assert float(got.min()) >= cfg['min_depth'] and float(got.max()) <= cfg['max_depth']
+
+
+@pytest.mark.gpu
+def test_depth_epilogue_full_size_properties_and_errors():
+    """C4-size batch (16 x 88 x 304 -> 16 x 352 x 1216), plain + flipped augmentation: equals the oracle; flipping an
+    augmentation's map and its flag together changes nothing; batch entries independent; NaN survives the clamp as in
+    torch.clamp; rows that are not a multiple of 4 wide take the scalar store path; bad arguments raise."""
+    from ddp_amd import _lib
+    from ddp_amd.engine import depth_postprocess
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    a, b = synthetic.make_depth_map(16, 88, 304, 50), synthetic.make_depth_map(16, 88, 304, 51)
+    got = depth_postprocess([a.cuda(), b.cuda()], [None, 'horizontal'], (352, 1216), 1e-3, 80.0)
+    ref = O.depth_postprocess([a, b], [None, 'horizontal'], (352, 1216), 1e-3, 80.0)
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * 80
+    same = depth_postprocess([a.cuda(), b.flip(dims=(3,)).cuda()], [None, None], (352, 1216), 1e-3, 80.0)
+    assert float((same - got).abs().max()) <= 2e-5 * 80       # resize commutes with the flip up to rounding
+    one = depth_postprocess([a[5:6].cuda(), b[5:6].cuda()], [None, 'horizontal'], (352, 1216), 1e-3, 80.0)
+    assert torch.equal(one[0], got[5])
+    odd = depth_postprocess([a[:1].cuda()], ['vertical'], (351, 1213), 1e-3, 80.0)           # 1213 % 4 != 0
+    assert float((odd.cpu() - O.depth_postprocess([a[:1]], ['vertical'], (351, 1213), 1e-3, 80.0)).abs().max()) <= 2e-5 * 80
+    n = a[:1].clone()
+    n[0, 0, 3, 7] = float('nan')
+    gn = depth_postprocess([n.cuda()], [None], (88, 304), 1e-3, 80.0).cpu()
+    assert torch.isnan(gn[0, 0, 3, 7]) and int(torch.isnan(gn).sum()) == 1
+    with pytest.raises(_lib.DdpError):
+        depth_postprocess([torch.zeros(1, 1, 4, 4)], [None], (16, 16), 1e-3, 80.0)             # CPU tensor: no CPU path
+    with pytest.raises(_lib.DdpError):
+        depth_postprocess([torch.zeros(1, 1, 4, 4).cuda()], [None], (16, 16), 80.0, 1e-3)      # empty depth range
+    with pytest.raises(ValueError):
+        depth_postprocess([torch.zeros(1, 2, 4, 4).cuda()], [None], (16, 16), 1e-3, 80.0)      # not a (B,1,h,w) map
+    with pytest.raises(ValueError):
+        depth_postprocess([torch.zeros(1, 1, 4, 4).cuda()] * 17, [None] * 17, (16, 16), 1e-3, 80.0)
+
+
+@pytest.mark.gpu
 def test_post_epilogue_full_size_properties():
     """C2-size scores (8,150,128,256) -> (8,512,1024): equals the oracle on a sampled image, flip == flipped map,
     batch entries independent."""

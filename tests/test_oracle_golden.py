@@ -113,6 +113,21 @@ def test_aug_test_golden(name):
     assert max_rel(p[0], prob) < TOL
 
 
+@pytest.mark.parametrize('name', case_names('dpost'))
+def test_depth_epilogue_golden(name):
+    """depth toolbox test entry (clamp / resize / flip-undo / mean over augmentations), fixtures made by calling the reference
+    model the way depth/depth/apis/test.py:88 does: ``model(return_loss=False, img=[...], img_metas=[[...]])``."""
+    from golden_util import load_dpost_case
+    cfg, maps, flips, out = load_dpost_case(name)
+    size = cfg['img'] if cfg['rescale'] else (cfg['augs'][0]['h'], cfg['augs'][0]['w'])
+    got = O.depth_postprocess(maps, flips, size, cfg['min_depth'], cfg['max_depth'], cfg['align_corners'])
+    assert got.shape == out.shape
+    assert torch.equal(got, out)                              # same torch ops on the same CPU: bit-exact
+    assert float(out.min()) >= cfg['min_depth'] and float(out.max()) <= cfg['max_depth']
+    assert float((torch.cat([m.flatten() for m in maps]) > cfg['max_depth']).float().mean()) > 0.01      # the clamp is exercised
+    assert float((torch.cat([m.flatten() for m in maps]) < cfg['min_depth']).float().mean()) > 0.01
+
+
 @pytest.mark.parametrize('name', case_names('neck'))
 def test_neck_golden(name):
     """MultiStageMerging, fixture made by the reference class."""

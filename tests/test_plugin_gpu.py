@@ -108,6 +108,91 @@ def test_depther_sample():
     assert o.shape == (1, 1, cfg['h'] * 4, cfg['w'] * 4) and float(o.min()) >= 1e-3 and float(o.max()) <= 80
 
 
+def _depth_model(cfg, sd, align_corners=False, min_depth=1e-3, max_depth=80):
+    dcfg = dict(type='DDP', bit_scale=cfg.get('bit_scale', 0.1), timesteps=cfg.get('timesteps', 3), randsteps=cfg.get('randsteps', 1),
+                min_depth=min_depth, max_depth=max_depth, test_cfg=dict(mode='whole'),
+                decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
+                                 dropout_ratio=0., scale_up=False, min_depth=min_depth, max_depth=max_depth, use_eps=True,
+                                 align_corners=align_corners, num_feature_levels=1, encoder=ENCODER, positional_encoding=POSENC))
+    model = ddp_amd.build_depther(dcfg)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize('name', ['dpost_kitti_flip', 'dpost_simple_hflip', 'dpost_vflip_ac3', 'dpost_norescale'])
+def test_depther_test_entry_matches_reference_fixture(name):
+    """The depth toolbox's harness call ``model(return_loss=False, **data)`` (depth/depth/apis/test.py:88,204) on the drop-in
+    class, end to end through forward -> forward_test -> simple_test / aug_test -> the fused epilogue, against what the
+    REFERENCE model returned for the same call (fixtures of gen_golden.py --task dpost; backbone and sampler replaced by the
+    same seeded low-resolution maps on both sides)."""
+    from golden_util import load_dpost_case
+    from ddp_amd.utils import synthetic
+    cfg, maps, flips, out = load_dpost_case(name)
+    model = _depth_model({}, synthetic.make_state_dict('depth', 1, 6, 256, seed=0), cfg['align_corners'], cfg['min_depth'], cfg['max_depth'])
+    model.extract_feat = lambda img: [None]
+    calls = []
+
+    def sample(x, img_metas=None, noise=None):
+        calls.append(1)
+        return maps[(len(calls) - 1) % len(maps)].cuda()
+    model.sample = sample
+    H, W = cfg['img']
+    data = dict(img=[torch.zeros(cfg['batch'], 3, H, W, device='cuda') for _ in flips],
+                img_metas=[[dict(img_shape=(H, W, 3), ori_shape=(H, W, 3), pad_shape=(H, W, 3), flip=f is not None,
+                                 flip_direction=f or 'horizontal')] * cfg['batch'] for f in flips])
+    res = model(return_loss=False, **data) if cfg['rescale'] else model(return_loss=False, rescale=False, **data)
+    assert isinstance(res, list) and len(res) == cfg['batch'] and len(calls) == len(flips)
+    assert res[0].dtype == out.numpy().dtype and res[0].shape == tuple(out.shape[1:])
+    err = float((torch.from_numpy(res[0]) - out[0]).abs().max())
+    assert err <= 2e-5 * cfg['max_depth'], err
+
+
+def test_depther_test_entry_end_to_end_vs_oracle():
+    """Same call, nothing stubbed but the backbone: KITTI's two augmentations (plain + horizontally flipped feature), each
+    through the full K-step loop with its own noise, then ONE epilogue kernel - against the oracle's loop + the reference's op
+    sequence for the epilogue.  Also: the protocol checks of base.py:62-92, a b = 2 batch, and simple_test == one augmentation."""
+    from oracle import ddp_oracle as O
+    cfg, sd, x, _, _, _ = load_case('depth_k3_r2')
+    model = _depth_model(cfg, sd)
+    h, w, r = cfg['h'], cfg['w'], cfg['randsteps']
+    H, W = 4 * h, 4 * w
+    xf = x.flip(dims=(3,))
+    feats = iter([x.cuda(), xf.cuda()])
+    model.extract_feat = lambda img: [next(feats)]
+    meta = dict(img_shape=(H, W, 3), ori_shape=(H, W, 3), pad_shape=(H, W, 3), flip=False, flip_direction='horizontal')
+    data = dict(img=[torch.zeros(1, 3, H, W, device='cuda')] * 2, img_metas=[[meta], [dict(meta, flip=True)]])
+    torch.manual_seed(5)
+    res = model(return_loss=False, **data)
+    torch.manual_seed(5)
+    n0 = torch.randn((1, r, 1, h, w), device='cuda').cpu()
+    n1 = torch.randn((1, r, 1, h, w), device='cuda').cpu()
+    kw = dict(timesteps=cfg['timesteps'], randsteps=r, bit_scale=cfg['bit_scale'], min_depth=cfg['min_depth'], max_depth=cfg['max_depth'])
+    ref = O.depth_postprocess([O.sample_depth(x, n0[0], sd, **kw), O.sample_depth(xf, n1[0], sd, **kw)], [None, 'horizontal'],
+                              (H, W), 1e-3, 80.0)
+    assert len(res) == 1 and res[0].shape == (1, H, W)
+    assert max_rel(torch.from_numpy(res[0]), ref[0]) < REL
+    # one augmentation == simple_test == inference; b = 2 images in one call
+    feats = iter([torch.cat([x, xf]).cuda()])
+    torch.manual_seed(6)
+    two = model(return_loss=False, img=[torch.zeros(2, 3, H, W, device='cuda')], img_metas=[[meta, meta]])
+    assert len(two) == 2 and two[0].shape == (1, H, W)
+    torch.manual_seed(6)
+    nb = torch.randn((2, r, 1, h, w), device='cuda').cpu()
+    for i, xi in enumerate((x, xf)):
+        refi = O.depth_postprocess([O.sample_depth(xi, nb[i], sd, **kw)], [None], (H, W), 1e-3, 80.0)
+        assert max_rel(torch.from_numpy(two[i]), refi[0]) < REL
+    # protocol errors of base.py:62-92 / encoder_decoder.py:183-187
+    with pytest.raises(TypeError):
+        model(return_loss=False, img=torch.zeros(1, 3, H, W, device='cuda'), img_metas=[[meta]])
+    with pytest.raises(ValueError):
+        model(return_loss=False, img=[torch.zeros(1, 3, H, W, device='cuda')] * 2, img_metas=[[meta]])
+    with pytest.raises(NotImplementedError):
+        model(return_loss=True, img=torch.zeros(1, 3, H, W, device='cuda'), img_metas=[meta])
+    model.test_cfg = dict(mode='slide')
+    with pytest.raises(NotImplementedError):
+        model(return_loss=False, img=[torch.zeros(1, 3, H, W, device='cuda')], img_metas=[[meta]])
+
+
 def test_bev_ddim_sample():
     cfg, sd, x, noise, _, g = load_case('bev_fusion')
     head = ddp_amd.BEVDeformableHeadWithTime(
