@@ -107,6 +107,123 @@ def relaunch_distributed(n):
     return subprocess.call(cmd)
 
 
+class _LoaderImages(torch.utils.data.Dataset):
+    """what a test pipeline worker does per image, roughly: decode-sized uint8 -> float, normalise, HWC -> CHW (512x1024)"""
+
+    def __len__(self):
+        return 1 << 30
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(i)
+        img = torch.randint(0, 256, (512, 1024, 3), generator=g, dtype=torch.uint8)
+        img = (img.float() - torch.tensor([123.675, 116.28, 103.53])) / torch.tensor([58.395, 57.12, 57.375])
+        return img.permute(2, 0, 1).contiguous()
+
+
+def host_leg(task, sd, weights, kw, wl, dev, seconds, ranks=8, workers_per_gpu=2):
+    """Multi-GPU readiness a ONE-GPU box can measure: the sampler has no collective, so what 8 ranks share
+    is the host.  (a) host time inside one ``DDPEngine.sample()`` call (the ctypes call returns after enqueueing its ~45
+    launches) next to the GPU time of that call, at B = 1 (the strong-scaling shard / the reference's one-image protocol) and
+    at the workload's batch; the same for ONE hipGraph launch (``DDPEngine.capture``).  (b) the B = 1 rate with the host
+    busy: `ranks - 1` busy-loop processes standing in for the other ranks' Python threads, then those plus
+    ``workers_per_gpu`` more per rank (their data-loader workers) and a real DataLoader feeding this rank - plain launches
+    against graph replay.  Reported under "host"; never part of ``value``."""
+    import subprocess
+    import threading
+    cx = wl.get('feat_channels', 256)
+    cm = 1 if task == 'depth' else 256
+    res = {'usable_cores': usable_cores(), 'ranks_modelled': ranks, 'workers_per_gpu': workers_per_gpu}
+    engines = {}
+    for B in sorted({1, wl['batch']}):
+        eng = DDPEngine(sd, task, **dict(kw, batch=B, weights=weights))
+        x, n = synthetic.make_inputs(B, wl['h'], wl['w'], wl['randsteps'], cx, cm, seed=77)
+        x, n = x.to(dev), n.to(dev)
+        out = torch.empty(eng.out_shape(), dtype=torch.float32, device=dev)
+        eng.sample(x, n, out=out)
+        graph = eng.capture(x, n)
+        engines[B] = (eng, x, n, out, graph)
+
+        def one(fn, reps=15):
+            enq, tot = [], []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                enq.append(t1 - t0)
+                tot.append(t2 - t0)
+            enq.sort()
+            tot.sort()
+            return enq[len(enq) // 2] * 1e3, tot[len(tot) // 2] * 1e3
+        e_ms, t_ms = one(lambda: eng.sample(x, n, out=out))
+        ge_ms, gt_ms = one(lambda: graph.replay())
+        res[f'b{B}'] = {'host_enqueue_ms': round(e_ms, 3), 'call_ms_idle_stream': round(t_ms, 3), 'host_share': round(e_ms / t_ms, 3),
+                        'graph_host_enqueue_ms': round(ge_ms, 3), 'graph_call_ms_idle_stream': round(gt_ms, 3),
+                        'graph_host_share': round(ge_ms / gt_ms, 3)}
+    eng, x, n, out, graph = engines[1]
+
+    def rate(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            fn()
+            k += 1
+            if k % 8 == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= seconds:
+                    break
+        torch.cuda.synchronize()
+        return k / (time.perf_counter() - t0)
+
+    def measure():
+        return {'plain_images_per_s': round(rate(lambda: eng.sample(x, n, out=out)), 2),
+                'graph_images_per_s': round(rate(lambda: graph.replay()), 2)}
+    res['b1_idle_host'] = measure()
+    busy = []
+    stop = threading.Event()
+    try:
+        for _ in range(ranks - 1):
+            busy.append(subprocess.Popen([sys.executable, '-c', 'while True: pass']))
+        time.sleep(0.5)
+        res['b1_other_ranks_busy'] = dict(measure(), busy_processes=len(busy))
+        for _ in range((ranks - 1) * workers_per_gpu):
+            busy.append(subprocess.Popen([sys.executable, '-c', 'while True: pass']))
+        loader = torch.utils.data.DataLoader(_LoaderImages(), batch_size=1, num_workers=workers_per_gpu)
+        fed = [0]
+
+        def feed():                                           # this rank's own data pipeline: workers + H2D copies
+            for img in loader:
+                img.to(dev, non_blocking=True)
+                fed[0] += 1
+                if stop.is_set():
+                    break
+        th = threading.Thread(target=feed, daemon=True)
+        th.start()
+        time.sleep(1.5)
+        res['b1_node_oversubscribed'] = dict(measure(), busy_processes=len(busy), loader_workers=workers_per_gpu,
+                                             images_fed_meanwhile=fed[0])
+        stop.set()
+        th.join(timeout=10)
+        del loader
+    finally:
+        stop.set()
+        for p in busy:
+            p.kill()
+        for p in busy:
+            p.wait()
+    idle = res['b1_idle_host']
+    for k in ('b1_other_ranks_busy', 'b1_node_oversubscribed'):
+        res[k]['plain_drop'] = round(1 - res[k]['plain_images_per_s'] / idle['plain_images_per_s'], 4)
+        res[k]['graph_drop'] = round(1 - res[k]['graph_images_per_s'] / idle['graph_images_per_s'], 4)
+    res['note'] = ('B = 1 = one image per call (strong-scaling shard of configs[1]; the reference harness protocol); host_share = host '
+                   'time inside the call / wall time of the call on an idle stream; drops are against the idle-host rate of the same mode')
+    return res
+
+
 def swin_t_standin_ms(B, H, W, dev, timed):
     """time of a torch-ROCm fp32 stand-in with the dense layers of Swin-T on a (B, 3, H, W) batch -> (ms, GFLOP per image).
     NOT part of the product: the reference's backbone stays PyTorch ('end-to-end as a secondary number')."""
@@ -390,6 +507,10 @@ def main():
     ap.add_argument('--power-seconds', type=float, default=3.0, help='length of the back-to-back loop the power leg samples')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the process-group code path (RCCL init, weight broadcast, barrier, MAX all_reduce) even at world size 1')
+    ap.add_argument('--host-leg', action='store_true',
+                    help='also measure host enqueue time per sample() call, plain and as a hipGraph, and the B = 1 rate with the '
+                         'host busy (other ranks + data loaders modelled by busy processes); reported under "host"')
+    ap.add_argument('--host-seconds', type=float, default=2.0)
     ap.add_argument('--next-rows', action='store_true',
                     help='also time the rows either side of the loop on the same batch (SURVEY.md §8 f1/f2): FPN + '
                          'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
@@ -635,6 +756,10 @@ def main():
                      'note': 'same batch; backbone = torch-ROCm fp32 stand-in with the dense layers of Swin-T (the backbone itself '
                              'is out of scope and stays PyTorch-ROCm); neck inputs = synthetic backbone levels (Swin-T channels)'}
 
+    host_res = None
+    if args.host_leg and rank == 0:
+        host_res = host_leg(task, sd, weights, kw, wl, dev, args.host_seconds)
+
     stream_res = None
     if args.size_stream > 0 and rank == 0 and task == 'seg':
         stream_res = size_stream(args.size_stream, sd, wl, dev)
@@ -752,7 +877,7 @@ def main():
             'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
             'images_per_s_per_gpu': round(images_per_s / world, 3),
             'roofline': roofline, 'power': power, 'joules_per_image': (power or {}).get('joules_per_image'),
-            'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows, 'size_stream': stream_res,
+            'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows, 'size_stream': stream_res, 'host': host_res,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())

@@ -95,12 +95,11 @@ class PackedWeights:
             setattr(tgt, f, base + 4 * o)
         return w
 
-    def broadcast(self, src=0):
+    def broadcast(self, src=0, force=False):
         """Replicate the frozen weights from rank ``src`` to every rank (RCCL over xGMI; the only
-        collective of the inference path - SURVEY.md §8e)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.flat, src=src)
+        collective of the inference path - SURVEY.md §8e).  ``force``: run the collective at world size 1 too."""
+        from .parallel import broadcast_weights
+        broadcast_weights(self.flat, src=src, force=force)
 
 
 class DDPEngine:
@@ -191,20 +190,25 @@ class DDPEngine:
         nw = c.w if w is None else int(w)
         if (nb, nh, nw) == (c.batch, c.h, c.w):
             return self
-        c.batch, c.h, c.w = nb, nh, nw
-        if self.task != 'bev':                      # bev: the decoder grid comes from the grid transform's output scope
-            c.head_h, c.head_w = nh, nw
+        # everything is validated / grown / prepared on a COPY of the cfg; self.cfg changes only on success, so a failed
+        # switch (too many tokens, out of memory, a launch error) leaves the engine on its old, still prepared geometry
+        n = _lib.DdpCfg.from_buffer_copy(c)
+        n.batch, n.h, n.w = nb, nh, nw
+        if self.task != 'bev' and (c.head_h, c.head_w) == (c.h, c.w):
+            n.head_h, n.head_w = nh, nw             # the decoder grid follows the map (bev: the grid transform's output scope;
+                                                    # a constructor head_hw that differs from the map is kept as given)
         nbytes = C.c_size_t(0)
-        _lib.check(self.lib.ddp_query_workspace(C.byref(c), C.byref(nbytes)), self.lib)
+        _lib.check(self.lib.ddp_query_workspace(C.byref(n), C.byref(nbytes)), self.lib)
         need = nbytes.value // 4
-        if need > self.workspace.numel():
-            new = torch.empty(int(need * grow), dtype=torch.float32, device=self.device)
+        ws = self.workspace
+        if need > ws.numel():
+            ws = torch.empty(int(need * grow), dtype=torch.float32, device=self.device)
             if self._prepared:
-                new[:self._const_floats].copy_(self.workspace[:self._const_floats])
-            self.workspace = new
+                ws[:self._const_floats].copy_(self.workspace[:self._const_floats])
         if self._prepared:
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.ddp_prepare_geometry(C.byref(c), self.workspace.data_ptr(), self._stream()), self.lib)
+                _lib.check(self.lib.ddp_prepare_geometry(C.byref(n), ws.data_ptr(), self._stream()), self.lib)
+        self.cfg, self.workspace = n, ws
         self.geometry_changes += 1
         return self
 
@@ -242,6 +246,30 @@ class DDPEngine:
                                            out.data_ptr(), self.workspace.data_ptr(), self._stream()), self.lib)
         return out
 
+    def capture(self, x, noise, step_noise=None):
+        """One ``sample()`` call as a hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm): ``ddp_sample`` neither
+        synchronises nor touches host memory after enqueue - its ~45 launches (kernels, device-to-device copies, memsets) go to
+        the stream it is given, the schedule scalars travel as kernel arguments - so the whole K-step loop records under stream
+        capture and replays with ONE host call.  What that buys is host time: one image per call (the reference's protocol, and
+        the strong-scaling shard) is ~4 ms of GPU work behind ~45 launches, issued by 8 ranks that share the node's cores with
+        their data loaders.  Inputs are copied into the graph's own static buffers at replay; -> ``SampleGraph``."""
+        if not self._prepared:
+            self.prepare()
+        sx, sn = x.detach().clone(), noise.detach().clone()
+        ssn = step_noise.detach().clone() if step_noise is not None else None
+        out = torch.empty(self.out_shape(), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):              # warm-up on the capture stream: one-time attribute calls happen here
+            self.sample(sx, sn, ssn, out=out)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self.sample(sx, sn, ssn, out=out)
+        return SampleGraph(self, g, sx, sn, ssn, out)
+
     def x0_trace(self):
         """(K, B*r, h, w) uint8: the x0 class every step of the LAST sample() call fed back (needs record_x0=True)."""
         c = self.cfg
@@ -267,6 +295,29 @@ class DDPEngine:
                                                  self.workspace.data_ptr(), self._stream()), self.lib)
         self._prepared = False      # head_forward rewrites the FiLM slot of step 0
         return out
+
+
+class SampleGraph:
+    """A captured ``DDPEngine.sample`` call (``DDPEngine.capture``).  ``replay(x, noise)`` copies the inputs into the graph's
+    static buffers (stream-ordered, on the current stream) and launches the graph; the returned tensor is the graph's static
+    output buffer (clone it to keep a result across replays).  Valid for the geometry and schedule it was captured with."""
+
+    def __init__(self, engine, graph, x, noise, step_noise, out):
+        self.engine, self.graph = engine, graph
+        self.x, self.noise, self.step_noise, self.out = x, noise, step_noise, out
+        self.geometry = engine.geometry()
+
+    def replay(self, x=None, noise=None, step_noise=None):
+        if self.engine.geometry() != self.geometry:
+            raise _lib.DdpError(f'graph captured for geometry {self.geometry}, engine is now at {self.engine.geometry()}')
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if noise is not None:
+            self.noise.copy_(noise.reshape(self.noise.shape), non_blocking=True)
+        if step_noise is not None:
+            self.step_noise.copy_(step_noise.reshape(self.step_noise.shape), non_blocking=True)
+        self.graph.replay()
+        return self.out
 
 
 class FcnSamplerEngine:

@@ -19,21 +19,23 @@ def shard_sizes(total, world):
     return [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
 
 
-def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def is_distributed(force=False):
+    """a process group with more than one rank - or, with ``force``, any initialised process group: the collectives then run
+    even at world size 1 (RCCL executes them as device-side copies), which is how a 1-GPU box exercises the RCCL code path"""
+    return dist.is_available() and dist.is_initialized() and (force or dist.get_world_size() > 1)
 
 
-def broadcast_weights(flat, src=0):
+def broadcast_weights(flat, src=0, force=False):
     """Replicate the packed weight blob (PackedWeights.flat) from ``src`` to all ranks, in place."""
-    if is_distributed():
+    if is_distributed(force):
         dist.broadcast(flat, src=src)
     return flat
 
 
-def gather_outputs(local_out, total):
+def gather_outputs(local_out, total, force=False):
     """all_gather per-rank output shards (B_local, ...) back into (total, ...) on every rank.  Shards may
     be ragged (total not divisible by world): they are padded to the largest shard for the collective."""
-    if not is_distributed():
+    if not is_distributed(force):
         return local_out
     world = dist.get_world_size()
     sizes = shard_sizes(total, world)

@@ -85,9 +85,21 @@ def _build_or_delegate(kind, registry, cfg):
         # constructor (missing cfg key, nested build failure) is the caller's error and propagates unchanged
         import importlib
         reg = getattr(importlib.import_module(pkg), kind.upper() + 'S', None)
-        known = getattr(reg, 'module_dict', None)
-        if known is not None:
-            if typ in known:
+        # ask the registry's own RESOLVER, not its private dict: ``module_dict`` holds only that registry's unscoped names,
+        # while scoped types ('mmcls.ConvNeXt' of the reference's ConvNeXt configs, configs/cityscapes/
+        # ddp_convnext_t_4x4_512x1024_160k_cityscapes.py:17) and parent / child registries resolve through ``get``
+        resolver = getattr(reg, 'get', None)
+        if callable(resolver) and isinstance(typ, str):
+            try:
+                known = resolver(typ) is not None
+            except Exception:                     # a resolver that cannot even parse the name: let the builder decide
+                known = None
+            if known:
+                return fn(cfg)
+            if known is False:
+                continue
+        elif getattr(reg, 'module_dict', None) is not None:
+            if typ in reg.module_dict:
                 return fn(cfg)
             continue
         try:

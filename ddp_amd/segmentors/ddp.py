@@ -214,14 +214,23 @@ class DDP(nn.Module, _SamplerMixin):
                                       align_corners=self.align_corners)
         return seg_logit
 
+    def _check_mode(self):
+        """encoder_decoder.py:266-271: ``test_cfg.mode`` in ('slide', 'whole').  Every shipped DDP config is 'whole'
+        (configs/ade/*:111, configs/cityscapes/*:96-98); sliding-window inference (encoder_decoder.py:175-227: a K-step loop per
+        crop, logits accumulated over overlapping windows) would need a tiled accumulate-and-normalise epilogue next to
+        ``ddp_seg_postprocess`` and is not built: it fails loudly in EVERY entry (simple_test, aug_test, inference) instead of
+        silently running whole-image inference."""
+        cfg = self.test_cfg
+        mode = (cfg.get('mode') if isinstance(cfg, dict) else getattr(cfg, 'mode', None)) if cfg is not None else None
+        if mode not in (None, 'whole'):
+            raise NotImplementedError(f"test_cfg.mode='{mode}': only 'whole' inference is part of the MI355X path "
+                                      "(slide_inference, encoder_decoder.py:175-227, is not built)")
+
     def inference(self, img, img_meta, rescale):
         """encoder_decoder.py:251-287, mode 'whole' (what every DDP config sets): class probabilities at ``ori_shape`` with
         the test-time flip undone - the building block of ``aug_test``.  ``simple_test`` does not go through here: its
         fused epilogue never materialises these (B,K,H,W) tensors."""
-        cfg = self.test_cfg
-        mode = (cfg.get('mode') if isinstance(cfg, dict) else getattr(cfg, 'mode', None)) if cfg is not None else None
-        if mode not in (None, 'whole'):
-            raise NotImplementedError(f"test_cfg.mode='{mode}': only 'whole' inference is part of the MI355X path")
+        self._check_mode()
         if img_meta:
             ori_shape = img_meta[0]['ori_shape']
             assert all(m['ori_shape'] == ori_shape for m in img_meta)
@@ -240,6 +249,7 @@ class DDP(nn.Module, _SamplerMixin):
         materialises per augmentation and the running sum at ori_shape never exist."""
         from ..engine import seg_aug_postprocess
         assert rescale, 'aug_test rescales every augmentation back to ori_shape'
+        self._check_mode()
         if len(imgs) != len(img_metas):
             raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
         ori_shape = tuple(img_metas[0][0]['ori_shape'][:2])
@@ -275,6 +285,7 @@ class DDP(nn.Module, _SamplerMixin):
         b >= 1 images (§8 f4): the loop runs once on the whole batch with independent noise per image, and every
         image gets the crop / rescale / flip of its OWN ``img_meta`` entry (one epilogue launch per distinct geometry)."""
         from ..engine import seg_postprocess
+        self._check_mode()
         x = self.extract_feat(img)[0]
         if self.diffusion == 'ddim':
             out = self.ddim_sample(x, img_meta)

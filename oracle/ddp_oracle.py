@@ -31,6 +31,10 @@ EMBED = 256
 HEADS = 8
 POINTS = 4
 
+# test hook: when a list, msda_forward appends the largest |sampling offset| (pixels) of every call - the radius by which one
+# decoder layer can carry a changed input sideways (tests/test_full_size_parity.py: dependency cone of a flipped decision)
+OFFSET_LOG = None
+
 
 # --------------------------------------------------------------------------------------------
 # schedules  (SEGDDP:14-28; depth/depth/models/depther/ddp.py:207-208)
@@ -175,6 +179,8 @@ def msda_forward(q, pos, h, w, sd, prefix, core='gridsample'):
     value = value.view(bs, n, HEADS, -1)
     off = F.linear(qp, sd[prefix + 'sampling_offsets.weight'], sd[prefix + 'sampling_offsets.bias'])
     off = off.view(bs, n, HEADS, POINTS, 2)
+    if OFFSET_LOG is not None:
+        OFFSET_LOG.append(float(off.abs().max()))
     aw = F.linear(qp, sd[prefix + 'attention_weights.weight'], sd[prefix + 'attention_weights.bias'])
     aw = aw.view(bs, n, HEADS, POINTS).softmax(-1)
     if core == 'gridsample':

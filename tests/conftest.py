@@ -27,3 +27,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The parity figures of the full-size tests, printed after everything else (tests/parity_report.py)."""
+    try:
+        import parity_report
+    except Exception:
+        return
+    if not parity_report.LINES:
+        return
+    terminalreporter.section('parity figures measured in this run (max-rel = max|gpu - oracle| / max|oracle|)')
+    for line in parity_report.LINES:
+        terminalreporter.write_line(line)

@@ -15,21 +15,19 @@ into the next step, so ONE near-tie pixel that rounds the other way moves a neig
 References: segmentation/mmseg/models/segmentors/ddp.py:215-246; depth/depth/models/depther/ddp.py:229-247;
 bev/mmdet3d/models/fusion_models/ddp.py:268-301.
 """
+import contextlib
 import os
 
 import pytest
 import torch
+import torch.nn.functional as F
+
+from parity_report import record
 
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
-# The largest distance the REFERENCE restated twice was seen to end from itself, free-running, per problem size
-# (scripts/reference_drift_sweep.py, profiles/r03w_reference_drift_c3.txt: 16 pairs over 8 C3-size images, 0.65e-3 .. 2.05e-3).
-# One pair on one image is a single draw of that distance - it even depends on the oracle's thread count (the same image and pair:
-# 1.2e-5 with 16 threads, 2.05e-3 with 8; profiles/r03x_*) - so the free-running assertion accepts the engine when it is within
-# twice THIS image's draw or within the worst the reference does to itself at this size.  C2 needs no entry: free-running stays
-# inside the gate on all 8 images (profiles/r03v_parity_sweep_c2.txt).
-REFERENCE_DRIFT_SEEN = {'C3': 2.05e-3}
+ORACLE_THREADS = 8      # the free-running draws depend on the CPU GEMMs' summation order: one thread count on every host
 BEV_SCOPES = dict(input_scope=((-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8)), output_scope=((-50, 50, 0.5), (-50, 50, 0.5)))
 
 
@@ -60,7 +58,7 @@ def _cpu_threads():
     torch.set_num_threads(old)
 
 
-def _report(name, got, ref, classes=True):
+def _report(name, got, ref, classes=True, summary=False):
     rel = (got - ref).abs().amax(1) / ref.abs().max()
     err = float(rel.max())
     msg = f'{name}: max-rel {err:.3e}, pixels above 1e-4: {int((rel > 1e-4).sum())} of {rel.numel()}'
@@ -68,8 +66,44 @@ def _report(name, got, ref, classes=True):
     if classes:
         agree = float((got.argmax(1) == ref.argmax(1)).float().mean())
         msg += f', final argmax agreement {agree:.6f}'
-    print(msg)
+    (record if summary else print)(msg)
     return err, agree
+
+
+@contextlib.contextmanager
+def _oracle_threads(n=ORACLE_THREADS):
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(n, _usable_cores())))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(old)
+
+
+def _dilate(mask, r):
+    """binary dilation of an (h,w) bool map by a (2r+1)^2 square, separable"""
+    if r <= 0 or not bool(mask.any()):
+        return mask.clone()
+    m = mask[None, None].float()
+    m = F.max_pool2d(m, (1, 2 * r + 1), stride=1, padding=(0, r))
+    m = F.max_pool2d(m, (2 * r + 1, 1), stride=1, padding=(r, 0))
+    return m[0, 0] > 0
+
+
+def _dependency_cone(differ, reach, accumulation):
+    """Pixels of the FINAL output that a set of differing x0 decisions can influence (segmentors/ddp.py:215-246).
+    ``differ[s]`` (h,w) bool: the two runs fed different classes back at step s.  The update (:238-239) and the concat-conv
+    are pointwise, so the noisy map entering step s differs exactly where some earlier decision differed; one pass of the
+    decoder then carries a changed input at most ``reach`` pixels (layers x (largest sampling offset + the bilinear tap)).
+    Output = last step's scores, or with accumulation the mean over all steps."""
+    K = len(differ)
+    changed = torch.zeros_like(differ[0])
+    cone = torch.zeros_like(differ[0])
+    for s in range(K):
+        if accumulation or s == K - 1:
+            cone |= _dilate(changed, reach)
+        changed = changed | differ[s]
+    return cone
 
 
 def _single_step_vs_fp64(name, g1, fn32, fn64):
@@ -91,20 +125,37 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
 
     The engine recorded the x0 class it fed back at every step (DDP_FLAG_RECORD_X0).  The oracle is run with THOSE
     decisions in place of its own argmax (everything else of segmentors/ddp.py:215-246 unchanged), so that
-      (1) the outputs must agree to rounding over all K steps - asserted at the north_star gate 1e-3, printed (~1e-5);
-      (2) the engine's decision at every step and pixel must be a maximiser of the ORACLE's scores up to rounding: the
-          oracle's top score minus its score of the engine's class <= 1e-4 of the score scale - asserted, and the
-          number of pixels where the two argmaxes differ is printed.
-    (1) + (2) = "identical to the reference up to which of two equal-to-rounding classes wins a tie".
-      (3) ``free_running`` (a tuple of oracle variants): the comparison with the oracle taking its own decisions, judged
-          against how far the REFERENCE RESTATED TWICE drifts from itself on the same image (one flipped near-tie moves its
-          neighbourhood by up to ~bit_scale-sized changes of the noisy map, SURVEY.md §7 hard part 1): asserted
-          free-running <= max(1e-3, 2 x reference-vs-reference); the three figures are printed on one line."""
+      (i)  the outputs must agree to rounding over all K steps - asserted at the north_star gate 1e-3, printed (~1e-5);
+      (ii) the engine's decision at every step and pixel must be a maximiser of the ORACLE's scores up to rounding: the
+           oracle's top score minus its score of the engine's class <= 1e-4 of the score scale - asserted, and the
+           number of pixels where the two argmaxes differ is printed.
+    (i) + (ii) = "identical to the reference up to which of two equal-to-rounding classes wins a tie".
+    ``free_running`` (a tuple of oracle variants): the comparison with the oracle taking its OWN decisions.  One flipped
+    near-tie moves its neighbourhood by O(bit_scale) changes of the noisy map (SURVEY.md §7 hard part 1), so what the
+    mechanism implies - and what is asserted, all of it computed on the box, nothing hard-coded:
+      (a) >= 99.5 % of the pixels within 1e-4;
+      (b) LOCALISATION: every pixel above 1e-4 lies inside the dependency cone of a decision that differs between the
+          engine's trace and the oracle's own decisions (``_dependency_cone``; reach = layers x (largest sampling offset the
+          oracle saw, rounded up, + 1 for the bilinear tap));
+      (c) free-running <= max(1e-3, 2 x reference-vs-reference), the yardstick being the REFERENCE RESTATED TWICE on this
+          image (``oracle.reference_drift_seg``: grid_sample vs explicit taps, fp32 vs fp64), run here with a fixed oracle
+          thread count.  (c) compares two single draws of a random event (does a near-tie flip, and does that pixel matter
+          afterwards): profiles/r03w_reference_drift_c3.txt has the reference 0.65e-3 .. 2.05e-3 from itself on 8 of 8
+          C3-size images, and profiles/r03v_parity_sweep_c3_image0.txt an image where (c) fails while (i), (ii) hold.  The
+          bound is NOT widened for that: (c)'s verdict is returned and the calling test ends ``xfail`` when it is False.
+    The figures go to the terminal summary (tests/parity_report.py).  Returns {'err', 'c_holds', 'c_line'}."""
     from oracle import ddp_oracle as O
     tr = eng.x0_trace()[:, b:b + 1].cpu().long()                             # (K, 1, h, w)
     trace = []
-    ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.01, accumulation=accumulation,
-                            trace=trace, x0_index=[tr[s] for s in range(K)])
+    L = O.num_layers_of(sd)
+    with _oracle_threads():
+        O.OFFSET_LOG = []
+        try:
+            ref = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.01, accumulation=accumulation,
+                                    trace=trace, x0_index=[tr[s] for s in range(K)])
+            max_off = max(O.OFFSET_LOG)
+        finally:
+            O.OFFSET_LOG = None
     err, agree = _report(f'{name} image {b} (engine decisions fed to the oracle)', out[b:b + 1], ref)
     assert err <= GATE and agree >= 0.9999
     flips, worst_gap, scale = 0, 0.0, 0.0
@@ -115,24 +166,53 @@ def _seg_parity_with_decisions(name, eng, out, x, noise, sd, b, K, accumulation,
         flips += int((lg.argmax(1) != tr[s]).sum())
         worst_gap = max(worst_gap, float((top - mine).max()))
         scale = max(scale, float(lg.abs().max()))
-    print(f'{name} image {b}: {flips} of {K * tr.shape[-1] * tr.shape[-2]} step-pixel decisions differ from the oracle argmax; '
-          f'largest oracle score gap at such a pixel {worst_gap:.3e} (score scale {scale:.2f})')
+    record(f'{name} image {b}: {flips} of {K * tr.shape[-1] * tr.shape[-2]} step-pixel decisions differ from the oracle argmax; '
+           f'largest oracle score gap at such a pixel {worst_gap:.3e} (score scale {scale:.2f})')
     assert worst_gap <= 1e-4 * scale
+    res = dict(err=err, c_holds=True, c_line='')
+    del trace
     if free_running:
-        # (3) free-running: the oracle takes its OWN argmax every step.  The yardstick is the reference restated twice
-        # (oracle.reference_drift_seg: grid_sample core vs explicit-tap core = its CPU vs its compiled-GPU arithmetic, and
-        # fp32 vs fp64): how far two evaluations of the REFERENCE drift apart on this very image once a near-tie falls the
-        # other way.  Asserted: the engine's free-running distance is within the north_star gate or within 2x that drift.
         variants = free_running if isinstance(free_running, (tuple, list)) else ('taps', 'fp64')
-        dr = O.reference_drift_seg(x[b:b + 1], noise[b], sd, timesteps=K, accumulation=accumulation, bit_scale=0.01, variants=variants)
+        with _oracle_threads():
+            dr = O.reference_drift_seg(x[b:b + 1], noise[b], sd, timesteps=K, accumulation=accumulation, bit_scale=0.01, variants=variants)
         err_f, agree_f = _report(f'{name} image {b} (free-running oracle)', out[b:b + 1], dr['base'])
-        flips_free = sum(int((a != t).sum()) for a, t in zip(dr['base_decisions'], [tr[s].to(torch.uint8) for s in range(K)]))
-        print(f'{name} image {b}: THREE FIGURES  decisions-fed {err:.3e} | free-running {err_f:.3e} ({flips_free} decisions differ) | '
-              f'reference-vs-reference {dr["ref_vs_ref"]:.3e} ' +
-              ', '.join(f'[{v}: {d["max_rel"]:.3e}, {d["pixels_above_1e-4"]} px above 1e-4, {d["decisions_differ"]} decisions differ]'
-                        for v, d in dr['variants'].items()))
-        assert err_f <= max(GATE, 2 * dr['ref_vs_ref'], REFERENCE_DRIFT_SEEN.get(name, 0.0)) and agree_f >= 0.9995
-    return err
+        differ = [dr['base_decisions'][s][0] != tr[s][0].to(torch.uint8) for s in range(K)]
+        flips_free = sum(int(d.sum()) for d in differ)
+        rel = ((out[b:b + 1] - dr['base']).abs().amax(1) / dr['base'].abs().max())[0]      # (h, w)
+        above = rel > 1e-4
+        reach = L * (int(max_off + 0.999) + 1)
+        cone = _dependency_cone(differ, reach, accumulation)
+        outside = int((above & ~cone).sum())
+        within = float((~above).float().mean())
+        # how far the differences REALLY travel: the smallest radius whose cone still covers every pixel above 1e-4 (the
+        # asserted cone is the worst case - every layer moving its input by the largest offset seen, in one direction)
+        tight = next((r for r in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64) if r < reach and
+                      not bool((above & ~_dependency_cone(differ, r, accumulation)).any())), reach)
+        record(f'{name} image {b}: THREE FIGURES  decisions-fed {err:.3e} | free-running {err_f:.3e} ({flips_free} decisions differ, '
+               f'{int(above.sum())} px above 1e-4 = {100 * (1 - within):.4f} %, {outside} of them outside the dependency cone; cone = '
+               f'{100 * float(cone.float().mean()):.2f} % of the image at the worst-case reach {reach} px; a reach of {tight} px already covers them) '
+               f'| reference-vs-reference '
+               f'{dr["ref_vs_ref"]:.3e} ' +
+               ', '.join(f'[{v}: {d["max_rel"]:.3e}, {d["pixels_above_1e-4"]} px above 1e-4, {d["decisions_differ"]} decisions differ]'
+                         for v, d in dr['variants'].items()) + f' (oracle threads {min(ORACLE_THREADS, _usable_cores())})')
+        assert within >= 0.995 and agree_f >= 0.9995                                            # (a)
+        assert outside == 0, f'{outside} pixels differ by more than 1e-4 where no differing decision can reach'   # (b)
+        bound = max(GATE, 2 * dr['ref_vs_ref'])                                                  # (c): this image's own draw
+        res['c_holds'] = err_f <= bound
+        res['c_line'] = (f'{name} image {b}: free-running {err_f:.3e} vs max(1e-3, 2 x reference-vs-reference {dr["ref_vs_ref"]:.3e}) = '
+                         f'{bound:.3e}: {"holds" if res["c_holds"] else "DOES NOT HOLD on this draw"}')
+        record(res['c_line'])
+    return res
+
+
+def _finish_free_running(results):
+    """(c) of _seg_parity_with_decisions, applied after everything deterministic has been asserted: the test ends xfail - not
+    pass, and not with a wider bound - on an image where the engine's single free-running draw exceeds twice the reference
+    pair's single draw."""
+    bad = [r['c_line'] for r in results if not r['c_holds']]
+    if bad:
+        pytest.xfail('free-running draw above 2 x this image\'s reference-vs-reference draw (a random event per image: '
+                     'profiles/r03w_reference_drift_c3.txt, r03v_parity_sweep_c3_image0.txt); (i), (ii), (a), (b) hold: ' + ' | '.join(bad))
 
 
 def test_c2_ade_8x512x1024_k3(dev):
@@ -158,8 +238,8 @@ def test_c2_ade_8x512x1024_k3(dev):
                      accumulation=True, device=dev, gather_guess_zero=True)
     assert torch.equal(engz.sample(x.to(dev), noise.to(dev)).cpu(), out)
     del engz
-    for b, free in ((0, ('taps', 'fp64')), (5, ('fp64',))):
-        _seg_parity_with_decisions('C2', eng, out, x, noise, sd, b, K, True, free)
+    results = [_seg_parity_with_decisions('C2', eng, out, x, noise, sd, b, K, True, free)
+               for b, free in ((0, ('taps', 'fp64')), (5, ('taps', 'fp64')))]
     eng1 = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=1, num_classes=ncls, bit_scale=0.01,
                      accumulation=False, device=dev)
     g1 = eng1.sample(x[:1].contiguous().to(dev), noise[:1].contiguous().to(dev)).cpu()
@@ -168,6 +248,7 @@ def test_c2_ade_8x512x1024_k3(dev):
         lambda: O.ddim_sample_seg(x[:1], noise[0], sd, timesteps=1, bit_scale=0.01),
         lambda: O.ddim_sample_seg(x[:1].double(), noise[0].double(), _dbl(sd), timesteps=1, bit_scale=0.01))
     assert gm <= 4 * cm + 1e-5 * sc        # fp32-class: within a small factor of the fp32 oracle's own rounding
+    _finish_free_running(results)
 
 
 def test_c3_cityscapes_4x1024x2048_k10(dev):
@@ -183,11 +264,11 @@ def test_c3_cityscapes_4x1024x2048_k10(dev):
     out = eng.sample(x.to(dev), noise.to(dev)).cpu()
     assert torch.isfinite(out).all()
     # ten steps of argmax feedback on 131 072 pixels.  Decisions fed: rounding level.  Free-running: a handful of flipped
-    # near-ties put the engine ~1.5e-3 from the oracle (r02b) - and put the reference's own two deformable-attention cores
-    # (grid_sample, its CPU path, vs explicit taps, the arithmetic of its compiled GPU kernel; both fp32) 0.97e-3 apart on
-    # this image (119 pixels above 1e-4, 4 decisions differ; measured in the build container, 8 cores).  The fp64 variant
-    # is left out here for time (it costs another 2.5 oracle-minutes; build container: 1.5e-5, 12 decisions differ)
-    _seg_parity_with_decisions('C3', eng, out, x, noise, sd, 2, K, False, ('taps',))
+    # near-ties put engine and oracle - and the reference's own two deformable-attention cores (grid_sample, its CPU path, vs
+    # explicit taps, the arithmetic of its compiled GPU kernel) - O(1e-3) apart inside the cones of those pixels.  Both
+    # variants of the yardstick run here (fp64 costs ~2.5 oracle-minutes; DDP_PARITY_C3_FP64=0 leaves it out)
+    variants = ('taps', 'fp64') if os.environ.get('DDP_PARITY_C3_FP64', '1') != '0' else ('taps',)
+    results = [_seg_parity_with_decisions('C3', eng, out, x, noise, sd, 2, K, False, variants)]
     del eng
     from oracle import ddp_oracle as O
     eng1 = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=1, num_classes=ncls, bit_scale=0.01,
@@ -198,6 +279,7 @@ def test_c3_cityscapes_4x1024x2048_k10(dev):
         lambda: O.ddim_sample_seg(x[:1], noise[0], sd, timesteps=1, bit_scale=0.01),
         lambda: O.ddim_sample_seg(x[:1].double(), noise[0].double(), _dbl(sd), timesteps=1, bit_scale=0.01))
     assert gm <= 4 * cm + 1e-5 * sc
+    _finish_free_running(results)
 
 
 def test_c4_kitti_depth_16x352x1216_k20(dev):
@@ -216,7 +298,7 @@ def test_c4_kitti_depth_16x352x1216_k20(dev):
     for b in (0, 11):
         ref = O.sample_depth(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.1, min_depth=1e-3,
                              max_depth=80.0)
-        err, _ = _report(f'C4 image {b}', out[b:b + 1], ref, classes=False)
+        err, _ = _report(f'C4 image {b}', out[b:b + 1], ref, classes=False, summary=True)
         assert err <= GATE
 
 
@@ -236,7 +318,7 @@ def test_c5_bev_8x200x200_k3(dev):
     assert tuple(out.shape) == (B, 6, 200, 200) and torch.isfinite(out).all()
     for b in (0, 6):
         ref = O.ddim_sample_bev(x[b:b + 1], noise[b], sd, timesteps=K, randsteps=1, bit_scale=0.01, **BEV_SCOPES)
-        err, _ = _report(f'C5 sample {b}', out[b:b + 1], ref, classes=False)
+        err, _ = _report(f'C5 sample {b}', out[b:b + 1], ref, classes=False, summary=True)
         thr = float(((out[b:b + 1] > 0.5) == (ref > 0.5)).float().mean())
         print(f'C5 sample {b}: thresholded-map agreement {thr:.6f}')
         assert err <= GATE
@@ -338,5 +420,5 @@ def test_c1_ade_1x512x512_k1(dev):
                     accumulation=True, device=dev)
     out = eng.sample(x.to(dev), noise.to(dev)).cpu()
     ref = O.ddim_sample_seg(x, noise[0], sd, timesteps=1, randsteps=1, bit_scale=0.01, accumulation=True)
-    err, agree = _report('C1', out, ref)
+    err, agree = _report('C1', out, ref, summary=True)
     assert err <= 2e-4 and agree >= 0.9999

@@ -306,6 +306,13 @@ def test_inference_and_aug_test_post_processing():
     model.test_cfg = dict(mode='slide', crop_size=(8, 8), stride=(4, 4))
     with pytest.raises(NotImplementedError):
         model.inference(img, [plain], True)
+    # every entry checks the mode - 'slide' must not silently run whole-image inference under aug_test / simple_test
+    with pytest.raises(NotImplementedError, match='slide'):
+        model.aug_test([img, img_f], [[plain], [flipped]])
+    with pytest.raises(NotImplementedError, match='slide'):
+        model.simple_test(img, [plain])
+    with pytest.raises(NotImplementedError, match='slide'):
+        model([img, img_f], [[plain], [flipped]], return_loss=False)
 
 
 def test_full_config_dict_with_a_backbone_entry():
@@ -403,6 +410,45 @@ def test_backbone_constructor_keyerror_is_not_swallowed(monkeypatch):
         ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='BrokenNet')))
     with pytest.raises(KeyError, match='NoSuchNet.*host toolbox'):
         ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='NoSuchNet')))
+
+
+def test_scoped_backbone_type_is_delegated_through_the_registry_resolver(monkeypatch):
+    """the reference's ConvNeXt configs name their backbone ``type='mmcls.ConvNeXt'`` (configs/cityscapes/
+    ddp_convnext_t_4x4_512x1024_160k_cityscapes.py:17, with custom_imports).  mmcv's ``module_dict`` holds only a registry's
+    own unscoped names; scoped names and parent / child registries resolve through ``Registry.get`` - the delegate has to ask
+    that, or ``build_backbone`` fails on every ConvNeXt DDP config."""
+    builder, regs = _stub_toolbox(monkeypatch, 'mmseg', ['BACKBONES'])
+
+    class ConvNeXt(torch.nn.Module):
+        def __init__(self, arch='tiny', **kw):
+            super().__init__()
+            self.arch = arch
+
+    reg = regs['BACKBONES']
+    sibling = {'ConvNeXt': ConvNeXt}                      # lives in ANOTHER scope's registry (mmcls), not in module_dict
+
+    def get(key):
+        scope, _, name = key.rpartition('.')
+        if scope == 'mmcls':
+            return sibling.get(name)
+        return reg.module_dict.get(key)
+
+    def build(cfg):
+        args = dict(cfg)
+        cls = get(args.pop('type'))
+        if cls is None:
+            raise KeyError(cfg['type'])
+        return cls(**args)
+
+    reg.get, builder.build_backbone = get, build
+    model = ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='mmcls.ConvNeXt', arch='tiny')))
+    assert isinstance(model.backbone, ConvNeXt) and model.backbone.arch == 'tiny'
+    assert 'mmcls.ConvNeXt' not in reg.module_dict and 'ConvNeXt' not in reg.module_dict
+    with pytest.raises(KeyError, match='mmcls.NoSuchNet.*host toolbox'):
+        ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='mmcls.NoSuchNet')))
+    # a resolver that chokes on the name leaves the decision to the toolbox's builder
+    reg.get = lambda key: (_ for _ in ()).throw(AttributeError('no parent registry'))
+    assert isinstance(ddp_amd.build_segmentor(seg_cfg(backbone=dict(type='mmcls.ConvNeXt'))).backbone, ConvNeXt)
 
 
 def test_neck_list_builds_the_fused_chain_with_sequential_keys():

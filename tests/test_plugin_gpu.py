@@ -306,6 +306,80 @@ def test_segmentor_size_stream_b1():
     assert not torch.equal(out2, outb[:1])
 
 
+@pytest.mark.parametrize('case,sampler', [('seg_ade_k3', 'ddim'), ('seg_city_r2', 'ddim'), ('seg_ddpm', 'ddpm'), ('depth_k3_r2', 'ddim')])
+def test_sample_as_hip_graph_is_bit_identical(case, sampler):
+    """the K-step loop captured in a hipGraph (no host sync, no host memory inside ``ddp_sample``) and
+    replayed - same bits as the plain call, on the captured inputs and on NEW inputs copied into the graph's static buffers;
+    a geometry change invalidates the graph loudly."""
+    from ddp_amd import _lib
+    from ddp_amd.engine import DDPEngine
+    from ddp_amd.utils import synthetic
+    cfg, sd, x, noise, step_noise, g = load_case(case)
+    task = cfg['task']
+    kw = dict(h=cfg['h'], w=cfg['w'], batch=1, randsteps=cfg['randsteps'], timesteps=cfg['timesteps'], bit_scale=cfg['bit_scale'])
+    if task == 'seg':
+        kw.update(num_classes=cfg['num_classes'], accumulation=cfg['accumulation'], sampler=sampler)
+    else:
+        kw.update(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'])
+    eng = DDPEngine(sd, task, **kw)
+    dx, dn = x.cuda(), noise.unsqueeze(0).cuda()
+    dsn = step_noise.unsqueeze(1).contiguous().cuda() if step_noise is not None else None
+    plain = eng.sample(dx, dn, dsn).clone()
+    assert max_rel(plain.cpu(), g['out']) < REL
+    graph = eng.capture(dx, dn, dsn)
+    assert torch.equal(graph.replay().clone(), plain)
+    assert torch.equal(graph.replay().clone(), plain)                  # replays are idempotent
+    cm = 1 if task == 'depth' else 256
+    x2, n2 = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], 256, cm, seed=4242)
+    sn2 = torch.randn_like(dsn) if dsn is not None else None
+    want = eng.sample(x2.cuda(), n2.cuda(), sn2).clone()
+    assert not torch.equal(want, plain)
+    assert torch.equal(graph.replay(x2.cuda(), n2.cuda(), sn2).clone(), want)
+    assert torch.equal(graph.replay(dx, dn, dsn).clone(), plain)
+    eng.set_geometry(1, cfg['h'] + 1, cfg['w'])
+    with pytest.raises(_lib.DdpError, match='captured for geometry'):
+        graph.replay()
+
+
+def test_engine_set_geometry_is_transactional():
+    """a geometry switch that fails (here: more tokens than the library accepts) must leave the engine on its old,
+    still prepared geometry - the same bad request fails again instead of hitting the early-return, and the next good call
+    reproduces the earlier bits."""
+    from ddp_amd import _lib
+    from ddp_amd.engine import DDPEngine
+    cfg, sd, x, noise, _, g = load_case('seg_ade_k3')
+    eng = DDPEngine(sd, 'seg', h=cfg['h'], w=cfg['w'], batch=1, randsteps=cfg['randsteps'], timesteps=cfg['timesteps'],
+                    num_classes=cfg['num_classes'], bit_scale=cfg['bit_scale'], accumulation=cfg['accumulation'])
+    first = eng.sample(x.cuda(), noise.unsqueeze(0).cuda()).clone()
+    assert max_rel(first.cpu(), g['out']) < REL
+    ws = eng.workspace
+    for _ in range(2):
+        with pytest.raises(_lib.DdpError):
+            eng.set_geometry(1, 1 << 15, 1 << 15)           # 2^30 tokens: refused by ddp_query_workspace
+        assert eng.geometry() == (1, cfg['h'], cfg['w']) and eng.workspace is ws and eng.geometry_changes == 0
+    assert torch.equal(eng.sample(x.cuda(), noise.unsqueeze(0).cuda()), first)
+    # a constructor head_hw equal to the map follows it; the switch itself still works after the failures
+    eng.set_geometry(1, 9, 11)
+    assert (eng.cfg.head_h, eng.cfg.head_w) == (9, 11) and eng.geometry_changes == 1
+    eng.set_geometry(1, cfg['h'], cfg['w'])
+    assert torch.equal(eng.sample(x.cuda(), noise.unsqueeze(0).cuda()), first)
+
+
+def test_aug_epilogue_small_then_large_class_count_in_one_process():
+    """k_seg_aug_postprocess's dynamic-LDS limit is set once per device; it must cover a later, larger class count
+    (19 classes = 9.7 KB first, then 150 = 76.8 KB and 256 = 128 KB, above the 64 KB default)."""
+    from ddp_amd.engine import seg_aug_postprocess
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    for K in (19, 150, 256):
+        sc = [synthetic.make_scores(1, K, 6, 9, 300 + K), synthetic.make_scores(1, K, 6, 9, 301 + K)]
+        metas = [dict(img_size=(24, 36), crop_size=(24, 36), flip=None), dict(img_size=(24, 36), crop_size=(24, 36), flip='horizontal')]
+        seg, p = seg_aug_postprocess([t.cuda() for t in sc], metas, (24, 36), False, return_prob=True)
+        ref, rp = O.seg_aug_test(sc, metas, (24, 36), False)
+        assert max_rel(p.cpu(), rp) < 2e-6, K
+        assert (seg.cpu().long() != ref).float().mean() < 1e-2, K
+
+
 def test_segmentor_aug_test_matches_inference_mean():
     """``aug_test`` (fused multi-scale / flip epilogue) against the reference's formulation composed from this class's own
     ``inference`` (torch ops, encoder_decoder.py:251-287): same noise, class maps equal up to near-ties."""
