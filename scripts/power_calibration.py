@@ -70,14 +70,15 @@ def vendor_gemm(m, n, k, seconds, dev):
     return rec
 
 
-def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0):
+def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0, dma=0, hbm=0):
     exe = os.path.join(ROOT, 'scripts', 'ubench', 'mfma_chip')
     if not os.path.exists(exe):
         return {'error': 'scripts/ubench/mfma_chip not built (hipcc --offload-arch=gfx950 -O2 mfma_chip.hip -o mfma_chip)'}
     ps = bench.PowerSampler()
     ps.start()
     t0 = time.perf_counter()
-    p = subprocess.run([exe, str(wps), str(chains), str(seconds), str(pattern), str(ldsr), str(valu)], capture_output=True, text=True, timeout=120)
+    p = subprocess.run([exe, str(wps), str(chains), str(seconds), str(pattern), str(ldsr), str(valu), str(dma), str(hbm)], capture_output=True,
+                       text=True, timeout=120)
     t1 = time.perf_counter()
     ps.stop()
     try:
@@ -132,6 +133,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=3.0)
     ap.add_argument('--sweep', action='store_true')
+    ap.add_argument('--components', action='store_true',
+                    help='only the attribution table of VERDICT r03 next #4: the layer kernel, then the MFMA + LDS-read + VALU mix alone, '
+                         '+ the LDS-DMA weight stream, + the HBM fragment streams (one box, one process, watts and MHz beside each)')
     ap.add_argument('--caps', default='1200,1000', help='package power caps (W) for the sweep')
     ap.add_argument('--clocks', default='1500', help='shader clock limits (MHz) for the sweep')
     args = ap.parse_args()
@@ -149,6 +153,19 @@ def main():
     torch.cuda.synchronize()
     res = {'headline': headline(eng, dx, dn, out, wl['batch'], args.seconds)}
     print('headline', json.dumps(res['headline']), file=sys.stderr, flush=True)
+    if args.components:
+        legs = [('mfma_only', (0, 0, 0, 0)), ('mix', (1, 3, 0, 0)), ('mfma+dma', (0, 0, 1, 0)), ('mix+dma', (1, 3, 1, 0)),
+                ('mix+hbm', (1, 3, 0, 1)), ('mix+dma+hbm', (1, 3, 1, 1)), ('mix (again)', (1, 3, 0, 0))]
+        res['components'] = []
+        for name, (l, v, d, hb) in legs:
+            rec = mfma_chip(1, 2, 1, args.seconds, l, v, d, hb)
+            rec['leg'] = name
+            res['components'].append(rec)
+            print(name, json.dumps(rec), file=sys.stderr, flush=True)
+        res['vendor_bf16_gemm'] = [vendor_gemm(8192, 8192, 8192, args.seconds, dev)]
+        res['headline_after'] = headline(eng, dx, dn, out, wl['batch'], args.seconds)
+        print(json.dumps(res))
+        return
     res['vendor_bf16_gemm'] = [vendor_gemm(8192, 8192, 8192, args.seconds, dev),
                                vendor_gemm(262144, 1024, 256, args.seconds, dev),       # fc1 of one launch (one of the 6 products)
                                vendor_gemm(262144, 256, 1024, args.seconds, dev)]      # fc2

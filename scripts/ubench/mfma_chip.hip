@@ -3,10 +3,18 @@
 // dense bf16 = 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz) assumes the nominal clock; under the 1400 W package cap the
 // part does not hold it while the matrix pipes are busy.  This loop measures that ceiling directly:
 //   mfma_chip <waves per SIMD: 1|2> <accumulator chains per wave: 2|4> <seconds> [operand pattern: 0 zeros | 1 random bits]
-//             [ds_read_b128 per two MFMAs: 0|1|2] [fp32 VALU fillers per MFMA: 0|2|3|4]
+//             [ds_read_b128 per two MFMAs: 0|1|2] [fp32 VALU fillers per MFMA: 0|2|3|4] [weight stream by LDS-DMA: 0|1] [HBM streams: 0|1]
 // The last two add what the layer kernel does around its MFMAs - the A fragments come out of LDS (random bits, a different
 // KiB every read) and independent v_fma_f32 fill the issue slots behind each MFMA - still without any global memory: how
 // much clock do those cost at the cap?
+// Round 4 (what is between this mix at 0.66 / 2.08 GHz and the layer kernel at 0.54 / 1.81 GHz?) adds the
+// layer kernel's two kinds of data movement, at its own densities, on top of the mix:
+//   weight stream   one global_load_lds_dwordx4 (1 KiB per wave, M0-addressed LDS-DMA) per 8 MFMAs = 128 B per MFMA, walking
+//                   a 4 MB buffer every block shares (the per-layer stream: resident in each XCD's 4 MB L2), into a
+//                   144 KiB LDS ring - 8.4 GB per 1.55 ms launch in the real kernel = 5.4 TB/s of L2 -> LDS traffic;
+//   HBM streams     per 128 MFMAs one 1-KiB non-temporal global_load_dwordx4 and one 1-KiB + (every 4th) a second
+//                   global_store_dwordx4 per wave, walking 1 GiB buffers (re-reference distance > the 256 MB MALL): the
+//                   activation fragments, 2 KiB read + 2.4 KiB written per token = ~0.9 TB/s at the kernel's rate.
 // Persistent grid (one block of 256 x waves-per-SIMD threads per CU); prints the achieved TFLOP/s and the cycles per MFMA
 // per SIMD from s_memtime.  scripts/power_calibration.py runs it while sampling amdsmi.
 // hipcc --offload-arch=gfx950 -O2 mfma_chip.hip -o mfma_chip
@@ -18,9 +26,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <int CHAINS, int LDSR, int VALU>
-__global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc, int iters, int pattern) {
-  __shared__ u32x4 lds[LDSR ? 3072 : 1];                  // 48 KiB: one stage image of the layer kernel (32 KiB of it are read)
+template <int CHAINS, int LDSR, int VALU, int DMA = 0, int HBM = 0>
+__global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc, int iters, int pattern, const u32x4* wstream,
+                                            const u32x4* hbm_in, u32x4* hbm_out) {
+  extern __shared__ u32x4 lds[];                          // 48 KiB stage image read by the fragments (+ 96 KiB more = the 3-slot ring with DMA)
   // operands: zeros (pattern 0: the multiplier array does not toggle) or pseudo-random bf16 bit patterns (random sign and mantissa, exponent of
   // 1.0 (pattern 1: what the split pieces of real activations look like to the datapath)
   unsigned s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
@@ -48,10 +57,56 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
   f32x16 acc[CHAINS];
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) acc[c] = f32x16{};
+  // weight stream: a block's 4 waves fetch 4 KiB per piece, consecutive pieces walk the 4 MB buffer; blocks start spread over it
+  const unsigned long long wbase = (unsigned long long)(size_t)wstream;
+  unsigned wpos = (blockIdx.x * 16384u) & (4u * 1024 * 1024 - 1);
+  const unsigned wlane = (threadIdx.x >> 6) * 1024u + lane * 16u;
+  unsigned ring = 0;
+  // HBM streams: 1 KiB per wave and event, the waves of the chip interleaved, wrapping at 1 GiB
+  const unsigned gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned nw = gridDim.x * (blockDim.x >> 6);
+  unsigned hpos = gw;
+  u32x4 pend = u32x4{0, 0, 0, 0};
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
+    if (HBM && (it & 7) == 0) {
+      // consume the fragment fetched 128 MFMAs ago (its wait is free by now), store a result fragment, fetch the next one
+      // (inline asm: a compiler-visible load / store makes hipcc put "s_waitcnt vmcnt(0..1)" in front of the next use of their
+      // registers, which - vector memory completes in order - drains every DMA piece issued since; the real kernel avoids that
+      // by front-loading its pieces.  Here the DMA issue's own vmcnt(11) already guarantees that anything older
+      // than the 11 youngest operations has landed, and this fetch is 16 pieces old when it is consumed.)
+      const u32x4 got = pend;
+      const size_t slot = size_t(hpos & (1u << 20) - 1) * 64 + lane;                    // 2^20 KiB = 1 GiB
+      const u32x4* src = hbm_in + slot;
+      u32x4* dst = hbm_out + slot;
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(pend) : "v"(src) : "memory");
+      u32x4 st = a[0];
+      st[0] ^= got[0] ^ got[1] ^ got[2] ^ got[3];
+      asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(st) : "memory");
+      if ((it & 31) == 0) {
+        u32x4* dst2 = hbm_out + (slot ^ (1u << 19) * 64);                                // 2.4 KiB written per 2 KiB read
+        asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst2), "v"(st) : "memory");
+      }
+      a[3][3] = (a[3][3] & 0x807F807Fu) | 0x3F803F80u | (got[0] & 0x007F007Fu);       // the fetched bits reach the multiplier array
+      hpos += nw;
+    }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
+      if (DMA && (u & 7) == 0) {
+        // the layer kernel's stream_piece: M0 = ring slot, 64 lanes x 16 B from (base + voff); at most 12 pieces in flight
+        const unsigned m0 = lds_base + 49152u + ring + (threadIdx.x >> 6) * 1024u;
+        const unsigned voff = ((wpos & (4u * 1024 * 1024 - 1)) + wlane);
+        asm volatile(
+            "s_waitcnt vmcnt(11)\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1"
+            :
+            : "v"(voff), "s"(wbase), "s"(__builtin_amdgcn_readfirstlane(m0))
+            : "memory");
+        wpos += 4096u;
+        ring = ring + 4096u >= 98304u ? 0u : ring + 4096u;
+      }
       // the fragment read here is consumed two operand rotations later
       // asm, so that the read stays HERE (the compiler would sink it next to its use and expose the LDS latency).  The counted
       // wait only bounds the reads in flight (a wait for the previous read - lgkmcnt(1) - stalls the wave for most of an LDS
@@ -89,8 +144,30 @@ int main(int argc, char** argv) {
   float* sink;
   unsigned long long* cyc;
   if (hipMalloc(&sink, size_t(cus) * threads * 4) != hipSuccess || hipMalloc(&cyc, size_t(cus) * threads / 64 * 8) != hipSuccess) return 1;
-  void (*kern)(float*, unsigned long long*, int, int) = nullptr;
-  if (chains == 4 && !ldsr && !valu) kern = k<4, 0, 0>;
+  const int dma = argc > 7 ? atoi(argv[7]) : 0, hbm = argc > 8 ? atoi(argv[8]) : 0;
+  u32x4 *wstream = nullptr, *hbm_in = nullptr, *hbm_out = nullptr;
+  if (dma) {
+    if (hipMalloc(&wstream, 4u << 20) != hipSuccess) return 1;
+    unsigned* hw = (unsigned*)malloc(4u << 20);
+    unsigned sd = 99991u;
+    for (size_t i = 0; i < (1u << 20); ++i) {
+      sd = sd * 1664525u + 1013904223u;
+      hw[i] = 0x3F803F80u | ((sd >> 8) & 0x807F807Fu);
+    }
+    (void)hipMemcpy(wstream, hw, 4u << 20, hipMemcpyHostToDevice);
+    free(hw);
+  }
+  if (hbm) {
+    if (hipMalloc(&hbm_in, size_t(1) << 30) != hipSuccess || hipMalloc(&hbm_out, size_t(1) << 30) != hipSuccess) return 1;
+    (void)hipMemset(hbm_in, 0x3c, size_t(1) << 30);
+  }
+  void (*kern)(float*, unsigned long long*, int, int, const u32x4*, const u32x4*, u32x4*) = nullptr;
+  if (dma || hbm) {
+    if (chains == 2 && ldsr == 1 && valu == 3 && dma == 1 && hbm == 0) kern = k<2, 1, 3, 1, 0>;
+    else if (chains == 2 && ldsr == 1 && valu == 3 && dma == 1 && hbm == 1) kern = k<2, 1, 3, 1, 1>;
+    else if (chains == 2 && ldsr == 1 && valu == 3 && dma == 0 && hbm == 1) kern = k<2, 1, 3, 0, 1>;
+    else if (chains == 2 && ldsr == 0 && valu == 0 && dma == 1 && hbm == 0) kern = k<2, 0, 0, 1, 0>;
+  } else if (chains == 4 && !ldsr && !valu) kern = k<4, 0, 0>;
   else if (chains == 2 && ldsr == 0 && valu == 0) kern = k<2, 0, 0>;
   else if (chains == 2 && ldsr == 1 && valu == 0) kern = k<2, 1, 0>;
   else if (chains == 2 && ldsr == 0 && valu == 2) kern = k<2, 0, 2>;
@@ -103,7 +180,11 @@ int main(int argc, char** argv) {
     fprintf(stderr, "combination not instantiated\n");
     return 2;
   }
-  auto launch = [&](int iters) { hipLaunchKernelGGL(kern, dim3(cus), dim3(threads), 0, 0, sink, cyc, iters, pattern); };
+  const int lds_bytes = dma ? 147456 : (ldsr ? 49152 : 16);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 3;
+  auto launch = [&](int iters) {
+    hipLaunchKernelGGL(kern, dim3(cus), dim3(threads), lds_bytes, 0, sink, cyc, iters, pattern, wstream, hbm_in, hbm_out);
+  };
   // calibrate the iteration count of one launch to ~50 ms, then launch back to back for the requested time
   launch(1000);
   (void)hipDeviceSynchronize();
@@ -125,8 +206,12 @@ int main(int argc, char** argv) {
   const double n_mfma = double(launches) * iters * 16.0 * cus * 4.0 * wps;     // wave-level instructions
   const double tflops = n_mfma * 32768.0 / (ms * 1e-3) / 1e12;
   // (s_memtime counts at a fixed 100 MHz on gfx950: cycles per MFMA = sampled shader clock / mfma_per_simd_per_s, by the caller)
-  printf("{\"waves_per_simd\": %d, \"chains\": %d, \"pattern\": %d, \"lds_reads_per_2_mfma\": %d, \"valu_per_mfma\": %d, \"cus\": %d, \"seconds\": %.3f, \"tflops_bf16\": %.1f, \"frac_of_2500\": %.4f, "
-         "\"mfma_per_simd_per_s\": %.4e}\n",
-         wps, chains, pattern, ldsr, valu, cus, ms * 1e-3, tflops, tflops / 2500.0, n_mfma / (cus * 4.0) / (ms * 1e-3));
+  // data moved per second by the two added streams (derived from the instruction counts, not measured)
+  const double mfma_per_wave_s = n_mfma / (cus * 4.0 * wps) / (ms * 1e-3);
+  const double dma_tbs = dma ? mfma_per_wave_s / 8.0 * 1024.0 * cus * 4.0 * wps / 1e12 : 0.0;
+  const double hbm_tbs = hbm ? mfma_per_wave_s / 128.0 * (1024.0 + 1024.0 * 1.25) * cus * 4.0 * wps / 1e12 : 0.0;
+  printf("{\"waves_per_simd\": %d, \"chains\": %d, \"pattern\": %d, \"lds_reads_per_2_mfma\": %d, \"valu_per_mfma\": %d, \"lds_dma_weight_stream\": %d, \"hbm_streams\": %d, \"cus\": %d, \"seconds\": %.3f, \"tflops_bf16\": %.1f, \"frac_of_2500\": %.4f, "
+         "\"mfma_per_simd_per_s\": %.4e, \"l2_to_lds_tb_per_s\": %.2f, \"hbm_tb_per_s\": %.2f}\n",
+         wps, chains, pattern, ldsr, valu, dma, hbm, cus, ms * 1e-3, tflops, tflops / 2500.0, n_mfma / (cus * 4.0) / (ms * 1e-3), dma_tbs, hbm_tbs);
   return 0;
 }
