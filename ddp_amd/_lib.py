@@ -15,7 +15,7 @@ ABI_VERSION = 5
 TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
-FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0, FLAG_GATHER_GUESS_ZERO = 1, 2, 4, 8
+FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0, FLAG_GATHER_GUESS_ZERO, FLAG_FCN_PREPARED = 1, 2, 4, 8, 16
 NECK_WEIGHTS_READY = 1
 
 _fp = C.c_void_p  # device pointers travel as raw addresses
@@ -82,7 +82,7 @@ MAX_AUGS = 16
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_query_const_workspace', 'ddp_prepare',
            'ddp_prepare_geometry', 'ddp_sample', 'ddp_msda_forward_lds_workspace', 'ddp_msda_forward_lds', 'ddp_seg_aug_postprocess', 'ddp_depth_postprocess',
            'ddp_x0_trace', 'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
-           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_neck_fpn_msm_workspace', 'ddp_neck_fpn_msm', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
+           'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_prepare_fcn', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_neck_fpn_msm_workspace', 'ddp_neck_fpn_msm', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
 _libs = {}
 
@@ -138,6 +138,8 @@ def load(path=None):
     lib.ddp_fcn_head_forward.argtypes = [C.POINTER(DdpFcnConv), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int,
                                          C.c_int, _fp, _fp, _fp]
     lib.ddp_sample_fcn_workspace.argtypes = [C.POINTER(DdpCfg), C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    lib.ddp_prepare_fcn.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpFcnConv), C.c_int, C.c_int,
+                                    C.POINTER(DdpStep), _fp, _fp]
     lib.ddp_sample_fcn.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpFcnConv), C.c_int, C.c_int,
                                    C.POINTER(DdpStep), _fp, _fp, _fp, _fp, _fp, _fp]
     lib.ddp_neck_fpn_workspace.argtypes = [C.POINTER(DdpFpnLevel), C.c_int, C.POINTER(C.c_size_t)]

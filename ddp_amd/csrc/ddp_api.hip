@@ -1708,12 +1708,56 @@ int ddp_fcn_head_workspace(int maps, int h, int w, int num_classes, size_t* byte
 }
 
 namespace {
+// constants of one head evaluation that depend on (weights, time embedding) only: per conv the 72 stage images of the scaled
+// 3x3 weights and the shift vector, conv_seg's 8 images and its padded bias
+struct FcnPrepared {
+  const unsigned char* conv_stream[8];
+  const float* conv_shift[8];
+  const unsigned char* cls_stream;
+  const float* cls_bias;
+};
+// one ConvWithTimeModule (fcn_head_with_time.py:205-225): FiLM vector from the time embedding, eval BatchNorm x FiLM folded
+// into (scale, shift), the scale folded into the 3x3 weights, those split and laid out as the 72 stage images of the stream
+// GEMM.  scratch = o.{film, aff, wpack, wsplit}
+int fcn_conv_prepare(const ddp_fcn_conv& c, int i, const float* d_temb, const FcnLayout& o, unsigned char* stream_dst,
+                     float* shift_dst, hipStream_t st) {
+  DDP_TRY(check_ptr(c.conv_w, "conv weight"));
+  if (c.bn_w && (!c.bn_b || !c.bn_mean || !c.bn_var)) {
+    set_error("fcn_head: conv %d has an incomplete norm", i);
+    return DDP_E_NULL;
+  }
+  const float* film = nullptr;
+  if (d_temb && c.time_w) {      // (:216-221) SiLU -> Linear(1024, 512) -> (scale | shift)
+    DDP_TRY(launch_matvec(c.time_w, c.time_b, d_temb, o.film, DDP_TIME_DIM, 512, 1, DDP_TIME_DIM, 512, 2, 0, st));
+    film = o.film;
+  }
+  DDP_TRY(launch_fcn_fold(c.bn_w, c.bn_b, c.bn_mean, c.bn_var, c.bn_eps, c.conv_b, film, o.aff, shift_dst, st));
+  DDP_TRY(launch_pack_conv3x3_scaled(c.conv_w, o.aff, o.wpack, 256, 256, st));
+  DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
+  return launch_build_stages(o.wsplit, size_t(256) * 2304, 2304, 256, 0, 1, 72, 0, 2, 1, 0, stream_dst, st);
+}
+// conv_seg (cls_seg; dropout is the identity in eval mode): 1x1, the class rows zero-padded to the GEMM's 256 outputs
+int fcn_cls_prepare(const float* d_cls_w, const float* d_cls_b, int num_classes, const FcnLayout& o, unsigned char* stream_dst,
+                    float* bias_dst, hipStream_t st) {
+  DDP_TRY(launch_split_weights(d_cls_w, 256, num_classes, 256, o.wsplit, st));
+  DDP_TRY(launch_build_stages(o.wsplit, size_t(num_classes) * 256, 256, num_classes, 0, 1, 8, 0, 2, 1, 0, stream_dst, st));
+  if (hipMemsetAsync(bias_dst, 0, 256 * sizeof(float), st) != hipSuccess ||
+      (d_cls_b && hipMemcpyAsync(bias_dst, d_cls_b, size_t(num_classes) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)) {
+    set_error("fcn_head: conv_seg bias copy failed");
+    return DDP_E_LAUNCH;
+  }
+  return DDP_OK;
+}
+
 // FCNHeadWithTime on token-major rows: o.x0 (M,256) in -> o.logits (M, ldl) (fcn_head_with_time.py:285-305, eval mode).  Inside,
 // the activations are fp32 fragment-major and every convolution runs on the persistent stream GEMM (k_layer MODE 5): the 3x3
-// ones as implicit GEMMs of 72 stages with the folded norm x FiLM shift as bias and ReLU in the epilogue, conv_seg as 8 stages
-// with the class rows zero-padded to 256.
+// ones as implicit GEMMs of 72 stages with the folded norm x FiLM shift as bias and ReLU in the epilogue, conv_seg as 8 stages.
+// `prep`: the weight-side constants built beforehand (the sampler loop: ddp_prepare_fcn); NULL: the time embedding is a
+// run-time input (ddp_fcn_head_forward) and they are built here, one conv at a time through the workspace's single stream
+// buffer (conv i's images are consumed - stream order - before conv i + 1's are written).
 int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, const float* d_cls_w, const float* d_cls_b,
-                    int num_classes, const float* d_temb, int maps, int h, int w, const FcnLayout& o, hipStream_t st) {
+                    int num_classes, const float* d_temb, int maps, int h, int w, const FcnLayout& o, hipStream_t st,
+                    const FcnPrepared* prep = nullptr) {
   const int N = h * w, M = maps * N;
   DDP_TRY(launch_row_to_blk(o.x0, o.xb0, M, st));
   float* cur = o.xb0;
@@ -1723,47 +1767,26 @@ int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, cons
   pr.gn_N = 0;
   pr.M = M;
   for (int i = 0; i < num_convs; ++i) {
-    const ddp_fcn_conv& c = convs[i];
-    DDP_TRY(check_ptr(c.conv_w, "conv weight"));
-    if (c.bn_w && (!c.bn_b || !c.bn_mean || !c.bn_var)) {
-      set_error("fcn_head: conv %d has an incomplete norm", i);
-      return DDP_E_NULL;
-    }
-    const float* film = nullptr;
-    if (d_temb && c.time_w) {      // (:216-221) SiLU -> Linear(1024, 512) -> (scale | shift)
-      DDP_TRY(launch_matvec(c.time_w, c.time_b, d_temb, o.film, DDP_TIME_DIM, 512, 1, DDP_TIME_DIM, 512, 2, 0, st));
-      film = o.film;
-    }
-    DDP_TRY(launch_fcn_fold(c.bn_w, c.bn_b, c.bn_mean, c.bn_var, c.bn_eps, c.conv_b, film, o.aff, o.aff + 256, st));
-    DDP_TRY(launch_pack_conv3x3_scaled(c.conv_w, o.aff, o.wpack, 256, 256, st));
-    DDP_TRY(launch_split_weights(o.wpack, 2304, 256, 2304, o.wsplit, st));
-    DDP_TRY(launch_build_stages(o.wsplit, size_t(256) * 2304, 2304, 256, 0, 1, 72, 0, 2, 1, 0, o.stream, st));
+    if (!prep) DDP_TRY(fcn_conv_prepare(convs[i], i, d_temb, o, o.stream, o.aff + 256, st));
     pr.A = cur;
     pr.out = nxt;
-    pr.stream = o.stream;
+    pr.stream = prep ? prep->conv_stream[i] : o.stream;
     pr.ns = 72;
     pr.conv_h = h;
     pr.conv_w = w;
-    pr.bias = o.aff + 256;
+    pr.bias = prep ? prep->conv_shift[i] : o.aff + 256;
     DDP_TRY(launch_b3_sgemm(&pr, 1, 2, dilation, st));
     float* t = cur;
     cur = nxt;
     nxt = t;
   }
-  // conv_seg (cls_seg; dropout is the identity in eval mode): 1x1, the class rows zero-padded to the GEMM's 256 outputs
-  DDP_TRY(launch_split_weights(d_cls_w, 256, num_classes, 256, o.wsplit, st));
-  DDP_TRY(launch_build_stages(o.wsplit, size_t(num_classes) * 256, 256, num_classes, 0, 1, 8, 0, 2, 1, 0, o.stream, st));
-  if (hipMemsetAsync(o.cls_bias, 0, 256 * sizeof(float), st) != hipSuccess ||
-      (d_cls_b && hipMemcpyAsync(o.cls_bias, d_cls_b, size_t(num_classes) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)) {
-    set_error("fcn_head: conv_seg bias copy failed");
-    return DDP_E_LAUNCH;
-  }
+  if (!prep) DDP_TRY(fcn_cls_prepare(d_cls_w, d_cls_b, num_classes, o, o.stream, o.cls_bias, st));
   pr.A = cur;
   pr.out = nxt;
-  pr.stream = o.stream;
+  pr.stream = prep ? prep->cls_stream : o.stream;
   pr.ns = 8;
   pr.conv_h = pr.conv_w = 0;
-  pr.bias = o.cls_bias;
+  pr.bias = prep ? prep->cls_bias : o.cls_bias;
   DDP_TRY(launch_b3_sgemm(&pr, 1, 0, 0, st));
   return launch_blk_to_row(nxt, o.logits, M, st, o.ldl, o.ldl);
 }
@@ -1773,9 +1796,13 @@ struct FcnLoopLayout {
   FcnLayout head;
   float *tin, *u, *hid, *temb, *lut, *wx, *wm, *xtok, *xproj, *mask, *prob, *snoise;
   unsigned short *wx_split, *wm_split, *in_sb;
+  // what ddp_prepare_fcn leaves behind for ddp_sample_fcn (besides temb, lut, wx_split, wm_split): per (step, conv) the stage
+  // images of the FiLM-scaled 3x3 weights and the shift vector; conv_seg's images and padded bias
+  unsigned char *conv_streams, *cls_stream;
+  float *conv_shifts, *cls_bias;
   size_t bytes;
 };
-int fcn_loop_layout(const ddp_cfg* c, char* base, FcnLoopLayout* o) {
+int fcn_loop_layout(const ddp_cfg* c, int num_convs, char* base, FcnLoopLayout* o) {
   const int R = c->batch * c->randsteps, N = c->h * c->w, Kc = c->num_classes, Cx = c->feat_channels;
   DDP_TRY(fcn_layout(R, c->h, c->w, Kc, base, &o->head));
   size_t off = o->head.bytes;
@@ -1802,8 +1829,25 @@ int fcn_loop_layout(const ddp_cfg* c, char* base, FcnLoopLayout* o) {
   o->snoise = takef(c->sampler == DDP_SAMPLER_DDPM ? M * 256 : 0);
   const size_t sb_a = MBp * Cx, sb_b = Mp * 256;
   o->in_sb = reinterpret_cast<unsigned short*>(take((sb_a > sb_b ? sb_a : sb_b) * 6));
+  const size_t per_conv = size_t(72) * b3_stage_bytes();
+  o->conv_streams = reinterpret_cast<unsigned char*>(take(size_t(c->timesteps) * num_convs * per_conv));
+  o->conv_shifts = takef(size_t(c->timesteps) * (num_convs > 0 ? num_convs : 1) * 256);
+  o->cls_stream = reinterpret_cast<unsigned char*>(take(size_t(8) * b3_stage_bytes()));
+  o->cls_bias = takef(256);
   o->bytes = off;
   return DDP_OK;
+}
+FcnPrepared fcn_prepared_of(const FcnLoopLayout& o, int num_convs, int step) {
+  FcnPrepared p;
+  const size_t per_conv = size_t(72) * b3_stage_bytes();
+  for (int i = 0; i < 8; ++i) {
+    const bool live = i < num_convs;
+    p.conv_stream[i] = live ? o.conv_streams + (size_t(step) * num_convs + i) * per_conv : nullptr;
+    p.conv_shift[i] = live ? o.conv_shifts + (size_t(step) * num_convs + i) * 256 : nullptr;
+  }
+  p.cls_stream = o.cls_stream;
+  p.cls_bias = o.cls_bias;
+  return p;
 }
 int validate_fcn_loop(const ddp_cfg* cfg, int num_convs, int dilation) {
   if (!cfg) {
@@ -1812,6 +1856,7 @@ int validate_fcn_loop(const ddp_cfg* cfg, int num_convs, int dilation) {
   }
   ddp_cfg c = *cfg;
   c.num_layers = 1;                       // the encoder depth is meaningless here
+  c.flags &= ~DDP_FLAG_FCN_PREPARED;      // this loop's own flag (ddp_sample rejects it)
   DDP_TRY(validate(&c));
   if (cfg->task != DDP_TASK_SEG || cfg->head_h != cfg->h || cfg->head_w != cfg->w) {
     set_error("sample_fcn: segmentation only (FCNHeadWithTime is a segmentation head)");
@@ -1852,14 +1897,14 @@ int ddp_sample_fcn_workspace(const ddp_cfg* cfg, int num_convs, int dilation, si
     return DDP_E_NULL;
   }
   FcnLoopLayout o;
-  DDP_TRY(fcn_loop_layout(cfg, nullptr, &o));
+  DDP_TRY(fcn_loop_layout(cfg, num_convs, nullptr, &o));
   *bytes = o.bytes;
   return DDP_OK;
 }
 
-int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
-                   const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
-                   void* d_workspace, void* stream) {
+namespace {
+int check_fcn_loop_args(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                        const ddp_step* steps, const void* d_workspace) {
   DDP_TRY(validate_fcn_loop(cfg, num_convs, dilation));
   if (!weights || !steps || (num_convs > 0 && !convs)) {
     set_error("sample_fcn: weights / steps / convs is NULL");
@@ -1871,17 +1916,12 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
   DDP_TRY(check_ptr(weights->head_w, "conv_seg weight"));
   DDP_TRY(check_ptr(weights->time1_w, "time_mlp.1"));
   DDP_TRY(check_ptr(weights->time3_w, "time_mlp.3"));
-  DDP_TRY(check_ptr(d_workspace, "workspace"));
-  DDP_TRY(check_ptr(d_x, "x"));
-  DDP_TRY(check_ptr(d_noise, "noise"));
-  DDP_TRY(check_ptr(d_out, "out"));
-  if (cfg->sampler == DDP_SAMPLER_DDPM) DDP_TRY(check_ptr(d_step_noise, "step_noise"));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  FcnLoopLayout o;
-  DDP_TRY(fcn_loop_layout(cfg, static_cast<char*>(d_workspace), &o));
-  const int B = cfg->batch, r = cfg->randsteps, K = cfg->timesteps, Kc = cfg->num_classes, Cx = cfg->feat_channels;
-  const int N = cfg->h * cfg->w, R = B * r, M = R * N;
-  // constants: time embeddings of every step, x0 LUT, the two column blocks of the concat-conv
+  return check_ptr(d_workspace, "workspace");
+}
+int prepare_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, const ddp_step* steps,
+                const FcnLoopLayout& o, hipStream_t st) {
+  const int K = cfg->timesteps, Kc = cfg->num_classes, Cx = cfg->feat_channels;
+  // time embeddings of every step, x0 LUT, the two column blocks of the concat-conv
   float tin[DDP_MAX_STEPS];
   for (int s = 0; s < K; ++s) tin[s] = steps[s].time_in;
   DDP_TRY(launch_write_floats(tin, K, o.tin, st));
@@ -1891,6 +1931,39 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
   DDP_TRY(launch_pack_cols(weights->transform_w, Cx + 256, Cx, 256, 256, o.wm, st));
   DDP_TRY(launch_split_weights(o.wx, Cx, 256, Cx, o.wx_split, st));
   DDP_TRY(launch_split_weights(o.wm, 256, 256, 256, o.wm_split, st));
+  // the head's weight-side constants: one set of scaled-weight images per (step, conv) - the FiLM scale depends on the step
+  const size_t per_conv = size_t(72) * b3_stage_bytes();
+  for (int s = 0; s < K; ++s)
+    for (int i = 0; i < num_convs; ++i)
+      DDP_TRY(fcn_conv_prepare(convs[i], i, o.temb + size_t(s) * DDP_TIME_DIM, o.head,
+                               o.conv_streams + (size_t(s) * num_convs + i) * per_conv,
+                               o.conv_shifts + (size_t(s) * num_convs + i) * 256, st));
+  return fcn_cls_prepare(weights->head_w, weights->head_b, Kc, o.head, o.cls_stream, o.cls_bias, st);
+}
+}  // namespace
+
+int ddp_prepare_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                    const ddp_step* steps, void* d_workspace, void* stream) {
+  DDP_TRY(check_fcn_loop_args(cfg, weights, convs, num_convs, dilation, steps, d_workspace));
+  FcnLoopLayout o;
+  DDP_TRY(fcn_loop_layout(cfg, num_convs, static_cast<char*>(d_workspace), &o));
+  return prepare_fcn(cfg, weights, convs, num_convs, steps, o, static_cast<hipStream_t>(stream));
+}
+
+int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                   const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
+                   void* d_workspace, void* stream) {
+  DDP_TRY(check_fcn_loop_args(cfg, weights, convs, num_convs, dilation, steps, d_workspace));
+  DDP_TRY(check_ptr(d_x, "x"));
+  DDP_TRY(check_ptr(d_noise, "noise"));
+  DDP_TRY(check_ptr(d_out, "out"));
+  if (cfg->sampler == DDP_SAMPLER_DDPM) DDP_TRY(check_ptr(d_step_noise, "step_noise"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FcnLoopLayout o;
+  DDP_TRY(fcn_loop_layout(cfg, num_convs, static_cast<char*>(d_workspace), &o));
+  const int B = cfg->batch, r = cfg->randsteps, K = cfg->timesteps, Kc = cfg->num_classes, Cx = cfg->feat_channels;
+  const int N = cfg->h * cfg->w, R = B * r, M = R * N;
+  if (!(cfg->flags & DDP_FLAG_FCN_PREPARED)) DDP_TRY(prepare_fcn(cfg, weights, convs, num_convs, steps, o, st));
   SplitW wpx, wpm;
   wpx.p = o.wx_split;
   wpx.comp_stride = size_t(256) * Cx;
@@ -1906,8 +1979,9 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
     // feat = transform(cat[x, mask_t]) -> the head's token-major input
     DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M, 256, st));
     DDP_TRY(launch_b3_linear(o.in_sb, wpm, nullptr, o.xproj, 256, r * N, N, o.head.x0, 256, M, 256, 256, st, TAG_XPROJ));
+    const FcnPrepared prep = fcn_prepared_of(o, num_convs, s);
     DDP_TRY(fcn_head_tokens(convs, num_convs, dilation, weights->head_w, weights->head_b, Kc, o.temb + size_t(s) * DDP_TIME_DIM, R,
-                            cfg->h, cfg->w, o.head, st));
+                            cfg->h, cfg->w, o.head, st, &prep));
     SegUpdateArgs a;
     a.logits = o.head.logits;
     a.ldl = o.head.ldl;

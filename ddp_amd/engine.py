@@ -355,9 +355,25 @@ class FcnSamplerEngine:
         nbytes = C.c_size_t(0)
         _lib.check(self.lib.ddp_sample_fcn_workspace(C.byref(cfg), head.num_convs, head.dilation, C.byref(nbytes)), self.lib)
         self.workspace = torch.empty(nbytes.value // 4 + 64, dtype=torch.float32, device=self.device)
+        self._prepared = False
+
+    def prepare(self):
+        """``ddp_prepare_fcn``: everything that depends on weights and schedule only (time embeddings, x0 table, concat-conv
+        column blocks, per (step, conv) FiLM -> folded affine -> scaled, split weights as stage images) once per engine; every
+        ``sample()`` afterwards runs with ``DDP_FLAG_FCN_PREPARED`` and launches none of those kernels."""
+        c = self.cfg
+        c.flags &= ~_lib.FLAG_FCN_PREPARED
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ddp_prepare_fcn(C.byref(c), C.byref(self.weights.struct), self.convs, self.head.num_convs,
+                                                self.head.dilation, self.steps, self.workspace.data_ptr(),
+                                                torch.cuda.current_stream(self.device).cuda_stream), self.lib)
+        c.flags |= _lib.FLAG_FCN_PREPARED
+        self._prepared = True
 
     def sample(self, x, noise, step_noise=None, out=None):
         c = self.cfg
+        if not self._prepared:
+            self.prepare()
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (c.batch, 256, c.h, c.w)
         assert noise.is_cuda and noise.is_contiguous() and noise.numel() == c.batch * c.randsteps * 256 * c.h * c.w
         if self.sampler == 'ddpm':

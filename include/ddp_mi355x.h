@@ -65,7 +65,8 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
  * GATHER_GUESS_ZERO: the LDS-staged gather starts every window from a zero guess of the head's mean sampling offset instead
  * of the mean of its offset biases, which forces its "actual mean is far from the guess: refill" branch (identical results:
  * the window origin only decides which taps are served from LDS). */
-enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8 };
+enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8,
+       DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */ };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -332,6 +333,15 @@ int ddp_fcn_head_forward(const ddp_fcn_conv* convs, int num_convs, int dilation,
  * x0 projection / update / accumulation as ddp_sample; cfg->task must be DDP_TASK_SEG, cfg->num_layers is ignored;
  * `weights` supplies transform, time_mlp, embedding and conv_seg (head_w / head_b), `convs` the head's ConvWithTimeModules. */
 int ddp_sample_fcn_workspace(const ddp_cfg* cfg, int num_convs, int dilation, size_t* bytes);
+/* Everything of that loop that depends on weights and schedule only - the time embeddings of the K steps, the x0 table, the
+ * split column blocks of the concat-conv and, per (step, conv), the FiLM vector (fcn_head_with_time.py:216-221), the folded
+ * norm x FiLM affine and the 72 stage images of the scaled 3x3 weights (the FiLM scale is folded INTO the weights, so every
+ * step has its own images), plus conv_seg's images - written once into the model region of the workspace.  A caller that
+ * samples repeatedly through the same workspace buffer (same stream, or after synchronising with this call) passes
+ * DDP_FLAG_FCN_PREPARED in cfg->flags to ddp_sample_fcn and none of these ~12 kernels per (step, conv) runs again; without
+ * the flag ddp_sample_fcn calls this itself. */
+int ddp_prepare_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
+                    const ddp_step* steps, void* d_workspace, void* stream);
 int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn_conv* convs, int num_convs, int dilation,
                    const ddp_step* steps, const float* d_x, const float* d_noise, const float* d_step_noise, float* d_out,
                    void* d_workspace, void* stream);

@@ -740,3 +740,23 @@ def test_sampler_loop_around_fcn_head_golden(dev, name):
     agree = (out.cpu().argmax(1) == g['out'].argmax(1)).float().mean().item()
     print(f'{name}: max-rel {err:.3e}, argmax agreement {agree:.4f}')
     assert err < REL and agree > 0.999
+    # the engine ran prepared (ddp_prepare_fcn once, then DDP_FLAG_FCN_PREPARED); a second call re-uses the constants and the
+    # self-preparing form of the C entry (flag off: every constant rebuilt inside the call) gives the same bits
+    import ctypes as C
+    from ddp_amd import _lib
+    eng = next(reversed(model._engine_cache.values()))
+    assert eng._prepared and (eng.cfg.flags & _lib.FLAG_FCN_PREPARED)
+    dx = x.to(dev)
+    dsn = step_noise.unsqueeze(1).contiguous().to(dev) if cfg['diffusion'] == 'ddpm' else None
+    again = eng.sample(dx, dn, dsn).clone()
+    assert torch.equal(again, out)
+    eng.workspace.zero_()                                      # nothing prepared any more
+    eng.cfg.flags &= ~_lib.FLAG_FCN_PREPARED
+    raw = torch.empty_like(out)
+    with torch.cuda.device(dev):
+        _lib.check(eng.lib.ddp_sample_fcn(C.byref(eng.cfg), C.byref(eng.weights.struct), eng.convs, eng.head.num_convs, eng.head.dilation,
+                                          eng.steps, dx.data_ptr(), dn.data_ptr(), dsn.data_ptr() if dsn is not None else None,
+                                          raw.data_ptr(), eng.workspace.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), eng.lib)
+    assert torch.equal(raw, out)
+    eng.cfg.flags |= _lib.FLAG_FCN_PREPARED                     # (the workspace holds the constants again: the call above rebuilt them)
+    assert torch.equal(eng.sample(dx, dn, dsn), out)
