@@ -78,9 +78,10 @@ class DdpDepthAug(C.Structure):
 
 
 MAX_AUGS = 16
+MAX_WINDOWS = 64
 
 EXPORTS = ['ddp_last_error', 'ddp_abi_version', 'ddp_query_workspace', 'ddp_query_const_workspace', 'ddp_prepare',
-           'ddp_prepare_geometry', 'ddp_sample', 'ddp_msda_forward_lds_workspace', 'ddp_msda_forward_lds', 'ddp_seg_aug_postprocess', 'ddp_depth_postprocess',
+           'ddp_prepare_geometry', 'ddp_sample', 'ddp_msda_forward_lds_workspace', 'ddp_msda_forward_lds', 'ddp_seg_aug_postprocess', 'ddp_seg_slide_postprocess', 'ddp_depth_postprocess',
            'ddp_x0_trace', 'ddp_head_forward', 'ddp_msda_forward', 'ddp_linear', 'ddp_linear_b3_workspace', 'ddp_linear_b3', 'ddp_time_embed', 'ddp_ddim_update_seg',
            'ddp_seg_x0_project', 'ddp_seg_postprocess', 'ddp_neck_msm_workspace', 'ddp_neck_msm', 'ddp_fcn_head_workspace', 'ddp_fcn_head_forward', 'ddp_sample_fcn_workspace', 'ddp_prepare_fcn', 'ddp_sample_fcn', 'ddp_neck_fpn_workspace', 'ddp_neck_fpn', 'ddp_neck_fpn_msm_workspace', 'ddp_neck_fpn_msm', 'ddp_profile_begin', 'ddp_profile_end', 'ddp_profile_read']
 
@@ -117,6 +118,7 @@ def load(path=None):
     lib.ddp_msda_forward_lds.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.ddp_seg_aug_postprocess.argtypes = [C.POINTER(DdpSegAug), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp,
                                             _fp]
+    lib.ddp_seg_slide_postprocess.argtypes = [C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int)] + [C.c_int] * 17 + [_fp, _fp, _fp]
     lib.ddp_depth_postprocess.argtypes = [C.POINTER(DdpDepthAug), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                           _fp, _fp]
     lib.ddp_sample.argtypes = [C.POINTER(DdpCfg), C.POINTER(DdpWeights), C.POINTER(DdpStep), _fp, _fp, _fp, _fp,

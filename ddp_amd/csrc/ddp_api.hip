@@ -1295,6 +1295,50 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
                                     static_cast<hipStream_t>(stream));
 }
 
+int ddp_seg_slide_postprocess(const float* const* d_scores, const int* win_y1, const int* win_x1, int n_rows, int n_cols, int batch,
+                              int num_classes, int h, int w, int crop_h, int crop_w, int img_h, int img_w, int keep_h, int keep_w,
+                              int out_h, int out_w, int align_corners, int flip, int prob_mode, unsigned char* d_seg, float* d_prob,
+                              void* stream) {
+  if (!d_scores || !win_y1 || !win_x1 || (!d_seg && !d_prob)) {
+    set_error("seg_slide_postprocess: scores / window origins / both outputs NULL");
+    return DDP_E_NULL;
+  }
+  if (n_rows < 1 || n_cols < 1 || n_rows * n_cols > DDP_MAX_WINDOWS || batch < 1 || num_classes < 1 || num_classes > 256 || h < 1 ||
+      w < 1 || crop_h < 1 || crop_w < 1 || crop_h > img_h || crop_w > img_w || keep_h < 1 || keep_w < 1 || keep_h > img_h ||
+      keep_w > img_w || out_h < 1 || out_w < 1 || flip < 0 || flip > 2 || prob_mode < 0 || prob_mode > 2 || (prob_mode && !d_prob)) {
+    set_error("seg_slide_postprocess: bad geometry (%dx%d windows of %dx%d on %dx%d, B %d K %d map %dx%d keep %dx%d out %dx%d flip %d "
+              "prob_mode %d)", n_rows, n_cols, crop_h, crop_w, img_h, img_w, batch, num_classes, h, w, keep_h, keep_w, out_h, out_w, flip,
+              prob_mode);
+    return DDP_E_BADCFG;
+  }
+  // every image pixel covered, by at most 3 window rows / columns (the kernel keeps that many per tap in registers)
+  for (int axis = 0; axis < 2; ++axis) {
+    const int* o = axis ? win_x1 : win_y1;
+    const int n = axis ? n_cols : n_rows, crop = axis ? crop_w : crop_h, size = axis ? img_w : img_h;
+    int covered = 0;
+    for (int i = 0; i < n; ++i) {
+      if (o[i] < 0 || o[i] + crop > size || (i > 0 && o[i] < o[i - 1]) || o[i] > covered) {
+        set_error("seg_slide_postprocess: window origins along axis %d must be ascending, inside the image and leave no gap", axis);
+        return DDP_E_BADCFG;
+      }
+      covered = o[i] + crop;
+      if (i >= 3 && o[i - 3] + crop > o[i]) {
+        set_error("seg_slide_postprocess: more than 3 windows overlap along axis %d (stride < crop / 3)", axis);
+        return DDP_E_BADCFG;
+      }
+    }
+    if (covered < size) {
+      set_error("seg_slide_postprocess: the windows do not cover the image along axis %d", axis);
+      return DDP_E_BADCFG;
+    }
+  }
+  for (int i = 0; i < n_rows * n_cols; ++i) DDP_TRY(check_ptr(d_scores[i], "window scores"));
+  if (d_prob) DDP_TRY(check_ptr(d_prob, "prob"));
+  return launch_seg_slide_postprocess(d_scores, win_y1, win_x1, n_rows, n_cols, batch, num_classes, h, w, crop_h, crop_w, img_h, img_w,
+                                      keep_h, keep_w, out_h, out_w, align_corners ? 1 : 0, flip, prob_mode, d_seg, d_prob,
+                                      static_cast<hipStream_t>(stream));
+}
+
 int ddp_depth_postprocess(const ddp_depth_aug* augs, int n_aug, int batch, int out_h, int out_w, int align_corners,
                           float min_depth, float max_depth, float* d_out, void* stream) {
   if (!augs) {

@@ -254,6 +254,9 @@ struct SegPostArgs {
 int launch_seg_postprocess(const SegPostArgs& a, hipStream_t st);
 int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K, int oh, int ow, int align, unsigned char* seg,
                                float* prob, hipStream_t st);
+int launch_seg_slide_postprocess(const float* const* scores, const int* y1, const int* x1, int n_rows, int n_cols, int B, int K, int h,
+                                 int w, int ch, int cw, int H, int W, int kh, int kw, int oh, int ow, int align, int flip, int prob_mode,
+                                 unsigned char* seg, float* prob, hipStream_t st);
 int launch_depth_aug_postprocess(const ddp_depth_aug* augs, int n_aug, int B, int oh, int ow, int align, float lo, float hi,
                                  float* out, hipStream_t st);
 // necks on fp32 fragment-major ("blk") activations - the stream GEMM's operand / result layout

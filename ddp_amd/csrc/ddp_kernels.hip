@@ -1004,6 +1004,99 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sliding-window inference epilogue (encoder_decoder.py:180-227 slide_inference + :266-296 inference / simple_test), fused: see
+// ddp_seg_slide_postprocess in the header.  One thread per output pixel.  Window coverage is separable (a grid of window rows
+// x columns), so per stage-2 tap the thread keeps the <= 3 covering rows and <= 3 covering columns with their stage-1
+// interpolation indices in registers and then walks the classes: value(tap, c) = sum over covering (row, col), row-major as
+// the reference adds them, of bilerp(window scores) / count.  LDS (prob output only): K x 64 floats, column = thread.
+// ------------------------------------------------------------------------------------------------
+struct SlideArgs {
+  const float* scores[DDP_MAX_WINDOWS];
+  int y1[DDP_MAX_WINDOWS], x1[DDP_MAX_WINDOWS];
+  int n_rows, n_cols, B, K, h, w, ch, cw, H, W, kh, kw, oh, ow, align, flip, prob_mode;
+  unsigned char* seg;
+  float* prob;
+};
+struct SlideCover {
+  int n;
+  int idx[3];
+  UpIdx u[3];
+};
+__device__ __forceinline__ SlideCover slide_cover(int p, const int* start, int n_win, int crop, int lowres, int align) {
+  SlideCover c;
+  c.n = 0;
+#pragma unroll 1
+  for (int i = 0; i < n_win; ++i)
+    if (p >= start[i] && p < start[i] + crop && c.n < 3) {
+      c.idx[c.n] = i;
+      c.u[c.n] = up_index(p - start[i], lowres, crop, align);
+      ++c.n;
+    }
+  return c;
+}
+__global__ void __launch_bounds__(64) k_seg_slide_postprocess(SlideArgs a) {
+  extern __shared__ float slide_lds[];
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x * 64 + tid;
+  const int y = blockIdx.y;
+  const int b = blockIdx.z;
+  if (x >= a.ow) return;
+  const int sx = a.flip == 1 ? a.ow - 1 - x : x;
+  const int sy = a.flip == 2 ? a.oh - 1 - y : y;
+  const bool two_stage = !(a.oh == a.kh && a.ow == a.kw);
+  const UpIdx Y = up_index(sy, a.kh, a.oh, a.align);
+  const UpIdx X = up_index(sx, a.kw, a.ow, a.align);
+  // stage-2 taps are image pixels (the crop to img_shape starts at the origin)
+  SlideCover cy[2], cx[2];
+  cy[0] = slide_cover(Y.i0, a.y1, a.n_rows, a.ch, a.h, a.align);
+  cx[0] = slide_cover(X.i0, a.x1, a.n_cols, a.cw, a.w, a.align);
+  cy[1] = two_stage ? slide_cover(Y.i1, a.y1, a.n_rows, a.ch, a.h, a.align) : cy[0];
+  cx[1] = two_stage ? slide_cover(X.i1, a.x1, a.n_cols, a.cw, a.w, a.align) : cx[0];
+  const size_t ps = size_t(a.h) * a.w;
+  const size_t boff = size_t(b) * a.K * ps;
+  auto tap = [&](const SlideCover& ry, const SlideCover& rx, int c) {
+    float s = 0.f;
+    for (int i = 0; i < ry.n; ++i)
+      for (int jx = 0; jx < rx.n; ++jx) {
+        const float* plane = a.scores[ry.idx[i] * a.n_cols + rx.idx[jx]] + boff + size_t(c) * ps;
+        const float* r0 = plane + size_t(ry.u[i].i0) * a.w;
+        const float* r1 = plane + size_t(ry.u[i].i1) * a.w;
+        const float v = bilerp(r0[rx.u[jx].i0], r0[rx.u[jx].i1], r1[rx.u[jx].i0], r1[rx.u[jx].i1], ry.u[i], rx.u[jx]);
+        s = (i == 0 && jx == 0) ? v : __fadd_rn(s, v);      // preds starts at zero: 0 + v == v
+      }
+    return s / float(ry.n * rx.n);                          // preds / count_mat
+  };
+  float best = -INFINITY, mx = -INFINITY;
+  int arg = 0;
+  for (int c = 0; c < a.K; ++c) {
+    float v = tap(cy[0], cx[0], c);
+    if (two_stage) v = bilerp(v, tap(cy[0], cx[1], c), tap(cy[1], cx[0], c), tap(cy[1], cx[1], c), Y, X);
+    if (a.prob_mode) slide_lds[c * 64 + tid] = v;
+    mx = fmaxf(mx, v);
+    if (v > best) {
+      best = v;
+      arg = c;
+    }
+  }
+  if (a.seg) a.seg[(size_t(b) * a.oh + y) * a.ow + x] = (unsigned char)arg;
+  if (a.prob_mode) {
+    float* pout = a.prob + (size_t(b) * a.K * a.oh + y) * a.ow + x;
+    const size_t cs = size_t(a.oh) * a.ow;
+    if (a.prob_mode == 2) {
+      for (int c = 0; c < a.K; ++c) pout[c * cs] = slide_lds[c * 64 + tid];
+    } else {
+      float sum = 0.f;
+      for (int c = 0; c < a.K; ++c) {
+        const float e = expf(slide_lds[c * 64 + tid] - mx);
+        slide_lds[c * 64 + tid] = e;
+        sum += e;
+      }
+      for (int c = 0; c < a.K; ++c) pout[c * cs] = slide_lds[c * 64 + tid] / sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Post-loop epilogue of the depth toolbox, fused (depth/depth/models/depther/ddp.py:95-109 encode_decode: clamp + resize;
 // encoder_decoder.py:187-194 inference: flip; :210-229 aug_test: running sum in list order, / n).  HBM-bound: the low-resolution
 // maps (<= 107 KB per image at KITTI size) stay in L2, the only real traffic is the (B,1,H,W) store, so a thread owns 4
@@ -1761,6 +1854,23 @@ int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K,
   attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), 2 * 256 * 64 * int(sizeof(float)));
   hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
   return check_launch("k_seg_aug_postprocess");
+}
+int launch_seg_slide_postprocess(const float* const* scores, const int* y1, const int* x1, int n_rows, int n_cols, int B, int K, int h,
+                                 int w, int ch, int cw, int H, int W, int kh, int kw, int oh, int ow, int align, int flip, int prob_mode,
+                                 unsigned char* seg, float* prob, hipStream_t st) {
+  SlideArgs a;
+  for (int i = 0; i < n_rows * n_cols; ++i) a.scores[i] = scores[i];
+  for (int i = 0; i < n_rows; ++i) a.y1[i] = y1[i];
+  for (int i = 0; i < n_cols; ++i) a.x1[i] = x1[i];
+  a.n_rows = n_rows; a.n_cols = n_cols; a.B = B; a.K = K; a.h = h; a.w = w; a.ch = ch; a.cw = cw; a.H = H; a.W = W;
+  a.kh = kh; a.kw = kw; a.oh = oh; a.ow = ow; a.align = align; a.flip = flip; a.prob_mode = prob_mode;
+  a.seg = seg;
+  a.prob = prob;
+  const int lds = prob_mode ? K * 64 * int(sizeof(float)) : 0;
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(k_seg_slide_postprocess), 256 * 64 * int(sizeof(float)));
+  hipLaunchKernelGGL(k_seg_slide_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
+  return check_launch("k_seg_slide_postprocess");
 }
 int launch_depth_aug_postprocess(const ddp_depth_aug* augs, int n_aug, int B, int oh, int ow, int align, float lo, float hi,
                                  float* out, hipStream_t st) {

@@ -449,6 +449,52 @@ def seg_aug_postprocess(scores_list, metas, out_size, align_corners=False, retur
     return (seg, prob) if return_prob else seg
 
 
+def slide_windows(img_hw, crop_size, stride):
+    """The window grid of ``slide_inference`` (encoder_decoder.py:186-206): -> (row origins y1, column origins x1, window size).
+    A crop larger than the image shrinks to the image ("the small patch will be used to decode without padding")."""
+    H, W = int(img_hw[0]), int(img_hw[1])
+    (h_crop, w_crop), (h_stride, w_stride) = crop_size, stride
+    h_grids = max(H - h_crop + h_stride - 1, 0) // h_stride + 1
+    w_grids = max(W - w_crop + w_stride - 1, 0) // w_stride + 1
+    ys = [max(min(i * h_stride + h_crop, H) - h_crop, 0) for i in range(h_grids)]
+    xs = [max(min(j * w_stride + w_crop, W) - w_crop, 0) for j in range(w_grids)]
+    return ys, xs, (min(h_crop, H), min(w_crop, W))
+
+
+def seg_slide_postprocess(scores, ys, xs, crop_hw, img_size, keep_size=None, out_size=None, align_corners=False, flip=None,
+                          want='seg'):
+    """Fused sliding-window epilogue (``ddp_seg_slide_postprocess``).  ``scores`` (n_rows*n_cols, B, K, h, w): the sampler's
+    low-resolution output for every window, row-major over the grid (ys x xs).  want: 'seg' -> uint8 class map (B,oh,ow);
+    'prob' -> softmax probabilities (B,K,oh,ow) (``inference``); 'scores' -> the window-averaged scores (``slide_inference``).
+    Replaces, per window, the resize of ``encode_decode`` and ``preds += F.pad(...)``, then ``/ count_mat``, crop, resize, softmax,
+    flip, argmax (encoder_decoder.py:180-227, 266-296).  CUDA tensors only; no CPU path."""
+    if not scores.is_cuda:
+        raise _lib.DdpError('seg_slide_postprocess: scores must be a CUDA tensor (no CPU path)')
+    n_rows, n_cols = len(ys), len(xs)
+    scores = scores.contiguous().float()
+    if scores.dim() != 5 or scores.shape[0] != n_rows * n_cols or n_rows * n_cols > _lib.MAX_WINDOWS:
+        raise ValueError(f'seg_slide_postprocess: scores (windows, B, K, h, w) with windows = {n_rows} x {n_cols} <= {_lib.MAX_WINDOWS}')
+    _, B, K, h, w = scores.shape
+    H, W = int(img_size[0]), int(img_size[1])
+    kh, kw = (H, W) if keep_size is None else (int(keep_size[0]), int(keep_size[1]))
+    oh, ow = (kh, kw) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    dev = scores.device
+    ptrs = (_lib._fp * (n_rows * n_cols))(*[scores[i].data_ptr() for i in range(n_rows * n_cols)])
+    y1 = (C.c_int * n_rows)(*[int(v) for v in ys])
+    x1 = (C.c_int * n_cols)(*[int(v) for v in xs])
+    seg = torch.empty((B, oh, ow), dtype=torch.uint8, device=dev) if want == 'seg' else None
+    prob = torch.empty((B, K, oh, ow), dtype=torch.float32, device=dev) if want != 'seg' else None
+    mode = {'seg': 0, 'prob': 1, 'scores': 2}[want]
+    fl = {None: 0, False: 0, 'horizontal': 1, 'vertical': 2}[flip]
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ddp_seg_slide_postprocess(ptrs, y1, x1, n_rows, n_cols, B, K, h, w, int(crop_hw[0]), int(crop_hw[1]), H, W, kh, kw,
+                                                 oh, ow, int(bool(align_corners)), fl, mode, seg.data_ptr() if seg is not None else None,
+                                                 prob.data_ptr() if prob is not None else None,
+                                                 torch.cuda.current_stream(dev).cuda_stream), lib)
+    return seg if want == 'seg' else prob
+
+
 def depth_postprocess(depth_list, flips, out_size, min_depth, max_depth, align_corners=False, out=None):
     """Fused post-loop epilogue of the depth toolbox (``ddp_depth_postprocess``): (B,1,out_h,out_w) fp32 from the low-resolution
     maps of every augmentation.  Replaces clamp -> bilinear resize (depth/depth/models/depther/ddp.py:95-109), the flip-undo of

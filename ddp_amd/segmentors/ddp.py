@@ -214,26 +214,68 @@ class DDP(nn.Module, _SamplerMixin):
                                       align_corners=self.align_corners)
         return seg_logit
 
-    def _check_mode(self):
-        """encoder_decoder.py:266-271: ``test_cfg.mode`` in ('slide', 'whole').  Every shipped DDP config is 'whole'
-        (configs/ade/*:111, configs/cityscapes/*:96-98); sliding-window inference (encoder_decoder.py:175-227: a K-step loop per
-        crop, logits accumulated over overlapping windows) would need a tiled accumulate-and-normalise epilogue next to
-        ``ddp_seg_postprocess`` and is not built: it fails loudly in EVERY entry (simple_test, aug_test, inference) instead of
-        silently running whole-image inference."""
+    def _mode(self):
+        """encoder_decoder.py:266-271: ``test_cfg.mode`` in ('slide', 'whole'); every shipped DDP config is 'whole'
+        (configs/ade/*:111, configs/cityscapes/*:96-98)."""
         cfg = self.test_cfg
         mode = (cfg.get('mode') if isinstance(cfg, dict) else getattr(cfg, 'mode', None)) if cfg is not None else None
-        if mode not in (None, 'whole'):
-            raise NotImplementedError(f"test_cfg.mode='{mode}': only 'whole' inference is part of the MI355X path "
-                                      "(slide_inference, encoder_decoder.py:175-227, is not built)")
+        if mode not in (None, 'whole', 'slide'):
+            raise AssertionError(f"test_cfg.mode must be 'slide' or 'whole', got {mode!r}")
+        return mode or 'whole'
+
+    def _sample(self, x, img_meta=None):
+        if self.diffusion == 'ddim':
+            return self.ddim_sample(x, img_meta)
+        if self.diffusion == 'ddpm':
+            return self.ddpm_sample(x, img_meta)
+        raise NotImplementedError
+
+    SLIDE_WINDOWS_PER_CALL = 16          # windows x images sampled in one call of the loop (memory bound of the workspace)
+
+    def _slide(self, img, img_meta, rescale, want, flip=None):
+        """Sliding-window inference (encoder_decoder.py:180-227).  The reference runs ``encode_decode`` - backbone, neck and a
+        K-step loop - window by window; the windows all have one size, so here they go through backbone + loop as ONE batch
+        (chunks of SLIDE_WINDOWS_PER_CALL maps, independent noise per window as in the reference) and only their LOW-RESOLUTION
+        scores are kept.  ``ddp_seg_slide_postprocess`` then does, per output pixel, what the reference does with image-size
+        tensors: resize per window, ``preds += pad(...)`` in window order, ``/ count_mat``, crop to img_shape, resize to
+        ori_shape, [softmax, flip-undo, argmax]."""
+        from ..engine import seg_slide_postprocess, slide_windows
+        cfg = self.test_cfg
+        get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        ys, xs, (ch, cw) = slide_windows(img.shape[2:], get('crop_size'), get('stride'))
+        b = img.shape[0]
+        crops = [img[:, :, y1:y1 + ch, x1:x1 + cw] for y1 in ys for x1 in xs]
+        per = max(1, self.SLIDE_WINDOWS_PER_CALL // b)
+        lows = []
+        for i in range(0, len(crops), per):
+            chunk = crops[i:i + per]
+            x = self.extract_feat(torch.cat(chunk, dim=0))[0]
+            lows.append(self._sample(x, img_meta).reshape(len(chunk), b, self.num_classes, x.shape[2], x.shape[3]))
+        scores = torch.cat(lows, dim=0)
+        keep = out = None
+        if rescale and img_meta:
+            keep = tuple(img_meta[0]['img_shape'][:2])
+            out = tuple(img_meta[0]['ori_shape'][:2])
+        return seg_slide_postprocess(scores, ys, xs, (ch, cw), img.shape[2:], keep, out, self.align_corners, flip, want)
+
+    def slide_inference(self, img, img_meta, rescale):
+        """encoder_decoder.py:180-227: the window-averaged scores (b,K,H,W) (at ori_shape when ``rescale``)."""
+        return self._slide(img, img_meta, rescale, 'scores')
 
     def inference(self, img, img_meta, rescale):
         """encoder_decoder.py:251-287, mode 'whole' (what every DDP config sets): class probabilities at ``ori_shape`` with
         the test-time flip undone - the building block of ``aug_test``.  ``simple_test`` does not go through here: its
         fused epilogue never materialises these (B,K,H,W) tensors."""
-        self._check_mode()
+        mode = self._mode()
         if img_meta:
             ori_shape = img_meta[0]['ori_shape']
             assert all(m['ori_shape'] == ori_shape for m in img_meta)
+        if mode == 'slide':
+            fl = None
+            if img_meta and img_meta[0].get('flip', False):
+                fl = img_meta[0].get('flip_direction', 'horizontal')
+                assert fl in ('horizontal', 'vertical')
+            return self._slide(img, img_meta, rescale, 'prob', fl)
         output = F.softmax(self.whole_inference(img, img_meta, rescale), dim=1)
         if img_meta and img_meta[0].get('flip', False):
             direction = img_meta[0].get('flip_direction', 'horizontal')
@@ -249,7 +291,14 @@ class DDP(nn.Module, _SamplerMixin):
         materialises per augmentation and the running sum at ori_shape never exist."""
         from ..engine import seg_aug_postprocess
         assert rescale, 'aug_test rescales every augmentation back to ori_shape'
-        self._check_mode()
+        if self._mode() == 'slide':
+            # no shipped config combines sliding windows with test-time augmentation: the reference's own composition
+            # (running mean of ``inference``, encoder_decoder.py:306-331) over the fused per-augmentation slide epilogue
+            prob = self.inference(imgs[0], img_metas[0], rescale)
+            for img, meta in zip(imgs[1:], img_metas[1:]):
+                prob += self.inference(img, meta, rescale)
+            prob /= len(imgs)
+            return list(prob.argmax(dim=1).cpu().numpy().astype('int64'))
         if len(imgs) != len(img_metas):
             raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
         ori_shape = tuple(img_metas[0][0]['ori_shape'][:2])
@@ -285,7 +334,11 @@ class DDP(nn.Module, _SamplerMixin):
         b >= 1 images (§8 f4): the loop runs once on the whole batch with independent noise per image, and every
         image gets the crop / rescale / flip of its OWN ``img_meta`` entry (one epilogue launch per distinct geometry)."""
         from ..engine import seg_postprocess
-        self._check_mode()
+        if self._mode() == 'slide':
+            if img_meta and any(self._epilogue_args(m, rescale) != self._epilogue_args(img_meta[0], rescale) for m in img_meta):
+                raise ValueError('slide inference: the images of a batch must share img_shape / ori_shape / flip')
+            fl = self._epilogue_args(img_meta[0], rescale)[2] if img_meta else None
+            return list(self._slide(img, img_meta, rescale, 'seg', fl).cpu().numpy().astype('int64'))
         x = self.extract_feat(img)[0]
         if self.diffusion == 'ddim':
             out = self.ddim_sample(x, img_meta)

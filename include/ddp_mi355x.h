@@ -251,6 +251,22 @@ typedef struct ddp_seg_aug {
 int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int num_classes, int out_h, int out_w,
                             int align_corners, unsigned char* d_seg, float* d_prob, void* stream);
 
+/* Sliding-window inference epilogue, fused (encoder_decoder.py:180-227 `slide_inference` over segmentors/ddp.py:114-129
+ * `encode_decode`, then :266-296 `inference` / `simple_test`): the image is covered by a grid of n_rows x n_cols windows of
+ * crop_h x crop_w pixels (top-left corners win_y1[i], win_x1[j]: the reference's y1 / x1 after clamping to the image); every
+ * window went through the K-step loop on its own and left low-resolution scores (B,K,h,w).  Per output pixel this kernel does
+ * what the reference does with full-size tensors: resize each covering window's scores to the window size, sum them in window
+ * order (row-major), divide by the number of covering windows, crop to (keep_h, keep_w) = img_shape, resize to (out_h, out_w) =
+ * ori_shape, [softmax,] undo the flip, argmax.  Neither the per-window (B,K,crop_h,crop_w) logits nor `preds` / `count_mat` at
+ * image size exist.  A pixel may be covered by at most 3 window rows and 3 window columns (stride >= crop / 3).
+ * d_scores[i * n_cols + j] (B,K,h,w); d_seg (B,out_h,out_w) uint8 or NULL; d_prob optional (B,K,out_h,out_w):
+ * prob_mode 1 = softmax probabilities (`inference`), 2 = the averaged scores themselves (`slide_inference`'s return value). */
+#define DDP_MAX_WINDOWS 64
+int ddp_seg_slide_postprocess(const float* const* d_scores, const int* win_y1, const int* win_x1, int n_rows, int n_cols, int batch,
+                              int num_classes, int h, int w, int crop_h, int crop_w, int img_h, int img_w, int keep_h, int keep_w,
+                              int out_h, int out_w, int align_corners, int flip, int prob_mode, unsigned char* d_seg, float* d_prob,
+                              void* stream);
+
 /* Post-loop epilogue of the depth toolbox, fused (depth/depth/models/depther/ddp.py:95-109 `encode_decode`: clamp to
  * [min_depth, max_depth], bilinear resize to the network input; encoder_decoder.py:187-194 `inference`: flip undone;
  * :198-209 `simple_test`; :210-229 `aug_test`: running sum over the augmentations in list order, / n).  One thread per 4

@@ -523,6 +523,33 @@ def seg_aug_test(scores_list, metas, out_size, align_corners=False):
     return acc.argmax(dim=1), acc
 
 
+def seg_slide_inference(window_scores, ys, xs, crop_hw, img_size, keep_size=None, out_size=None, align_corners=False):
+    """Sliding-window inference, the reference's own op sequence (encoder_decoder.py:180-227 over segmentors/ddp.py:114-129):
+    per window (row-major over the grid ys x xs) the sampler's low-resolution scores are resized to the window size
+    (``encode_decode``) and added into ``preds`` through ``F.pad``; ``preds / count_mat``; crop to img_shape and resize to
+    ori_shape when rescaling.  window_scores[i] (B,K,h,w) -> (B,K,out_h,out_w) averaged scores (softmax / flip / argmax:
+    ``inference`` / ``simple_test``, :273-296, as in seg_postprocess)."""
+    H, W = img_size
+    ch, cw = crop_hw
+    B, K = window_scores[0].shape[:2]
+    preds = torch.zeros((B, K, H, W))
+    count = torch.zeros((B, 1, H, W))
+    i = 0
+    for y1 in ys:
+        for x1 in xs:
+            logit = F.interpolate(window_scores[i], size=(ch, cw), mode='bilinear', align_corners=align_corners)
+            preds += F.pad(logit, (int(x1), int(W - x1 - cw), int(y1), int(H - y1 - ch)))
+            count[:, :, y1:y1 + ch, x1:x1 + cw] += 1
+            i += 1
+    assert (count == 0).sum() == 0
+    preds = preds / count
+    if keep_size is not None:
+        preds = preds[:, :, :keep_size[0], :keep_size[1]]
+        preds = F.interpolate(preds, size=tuple(out_size if out_size is not None else keep_size), mode='bilinear',
+                              align_corners=align_corners)
+    return preds
+
+
 def depth_postprocess(depth_list, flips, out_size, min_depth, max_depth, align_corners=False):
     """Post-loop epilogue of the depth toolbox, the reference's own op sequence: per augmentation ``encode_decode``
     (depth/depth/models/depther/ddp.py:95-109: clamp to the head's depth range, resize to the network input) and the flip-undo

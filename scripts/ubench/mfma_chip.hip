@@ -73,8 +73,11 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
       // consume the fragment fetched 128 MFMAs ago (its wait is free by now), store a result fragment, fetch the next one
       // (inline asm: a compiler-visible load / store makes hipcc put "s_waitcnt vmcnt(0..1)" in front of the next use of their
       // registers, which - vector memory completes in order - drains every DMA piece issued since; the real kernel avoids that
-      // by front-loading its pieces.  Here the DMA issue's own vmcnt(11) already guarantees that anything older
-      // than the 11 youngest operations has landed, and this fetch is 16 pieces old when it is consumed.)
+      // by front-loading its pieces.  Here the wait is explicit and counted: 16 DMA pieces have been issued since
+      // the fetch consumed now, so vmcnt(16) = "the fetch and the stores of the previous event have landed", the pieces stay in
+      // flight.  Without any wait a late-landing fetch overwrites a re-used address register: r04b faulted exactly that way.)
+      if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const u32x4 got = pend;
       const size_t slot = size_t(hpos & (1u << 20) - 1) * 64 + lane;                    // 2^20 KiB = 1 GiB
       const u32x4* src = hbm_in + slot;
@@ -93,11 +96,13 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       if (DMA && (u & 7) == 0) {
-        // the layer kernel's stream_piece: M0 = ring slot, 64 lanes x 16 B from (base + voff); at most 12 pieces in flight
+        // the layer kernel's stream_piece: M0 = ring slot, 64 lanes x 16 B from (base + voff); at most 24 pieces in flight = the
+        // two stages of look-ahead of the kernel's 3-slot ring (with 12 the loop is bound by DMA latency x concurrency, not by power:
+        // profiles/r04b_power_components_12_in_flight.json - 1.7 - 2.2 us per piece under load, 5.6 TB/s instead of the 7.1 demanded)
         const unsigned m0 = lds_base + 49152u + ring + (threadIdx.x >> 6) * 1024u;
         const unsigned voff = ((wpos & (4u * 1024 * 1024 - 1)) + wlane);
         asm volatile(
-            "s_waitcnt vmcnt(11)\n\t"
+            "s_waitcnt vmcnt(23)\n\t"
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
             "global_load_lds_dwordx4 %0, %1"

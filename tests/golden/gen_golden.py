@@ -375,6 +375,61 @@ def gen_aug():
                   scores_fp=np.stack([fingerprint(t) for t in scores])))
 
 
+SLIDE_CASES = [
+    # Cityscapes-like: 3 x 3 overlapping windows, image == img_shape == ori_shape (one resize per window, no second stage)
+    dict(name='slide_city_3x3', num_classes=19, img=(64, 128), crop_size=(32, 64), stride=(21, 43), h=8, w=16, img_shape=(64, 128),
+         ori_shape=(64, 128), flip=None, align_corners=False, seed=0),
+    # padded input cropped to img_shape, enlarged to ori_shape, horizontal flip; last windows clamped back into the image
+    dict(name='slide_crop_resize_hflip', num_classes=19, img=(48, 80), crop_size=(32, 32), stride=(20, 20), h=8, w=8, img_shape=(45, 77),
+         ori_shape=(61, 99), flip='horizontal', align_corners=False, seed=1),
+    # crop larger than the image in one dimension ("the small patch will be used"), 150 classes, align_corners, vertical flip
+    dict(name='slide_small_image_ac', num_classes=150, img=(24, 72), crop_size=(32, 32), stride=(16, 24), h=6, w=8, img_shape=(24, 70),
+         ori_shape=(30, 64), flip='vertical', align_corners=True, seed=2),
+]
+
+
+def gen_slide():
+    """Sliding-window inference (encoder_decoder.py:180-227) through the reference's own simple_test / inference /
+    slide_inference / DDP.encode_decode; backbone and sampler replaced by seeded low-resolution scores, one per window."""
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    from ddp_amd.engine import slide_windows
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in SLIDE_CASES:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.test_cfg.mode = 'slide'
+        m.test_cfg.crop_size = tuple(case['crop_size'])
+        m.test_cfg.stride = tuple(case['stride'])
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        model.align_corners = case['align_corners']
+        ys, xs, (ch, cw) = slide_windows(case['img'], case['crop_size'], case['stride'])
+        n_win = len(ys) * len(xs)
+        scores = [synthetic.make_scores(1, case['num_classes'], case['h'], case['w'], case['seed'] * 100 + i) for i in range(n_win)]
+        calls = []
+        shapes = []
+        model.extract_feat = lambda img, _s=shapes: (_s.append(tuple(img.shape[2:])), [None])[1]
+
+        def sample(x, img_metas, _calls=calls, _scores=scores):
+            _calls.append(1)
+            return _scores[(len(_calls) - 1) % len(_scores)].clone()
+        model.ddim_sample = sample
+        img = torch.zeros((1, 3) + tuple(case['img']))
+        meta = [dict(img_shape=tuple(case['img_shape']) + (3,), ori_shape=tuple(case['ori_shape']) + (3,),
+                     pad_shape=tuple(case['img']) + (3,), flip=case['flip'] is not None, flip_direction=case['flip'] or 'horizontal')]
+        seg = model.simple_test(img, meta, rescale=True)[0]
+        assert len(calls) == n_win and all(s == (ch, cw) for s in shapes), (len(calls), n_win, shapes[:3], (ch, cw))
+        prob = model.inference(img, meta, True)
+        assert (prob.argmax(1)[0].numpy() == seg).all()
+        top2 = prob.topk(2, dim=1).values
+        save(case['name'], dict(task='slide', n_windows=n_win, **case),
+             dict(seg=seg.astype('uint8'), prob=prob[0], margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=np.stack([fingerprint(t) for t in scores])))
+
+
 DPOST_CASES = [
     # KITTI test pipeline (depth/configs/_base_/datasets/kitti.py:26-41): 352 x 1216 after KBCrop, plain + horizontal flip
     dict(name='dpost_kitti_flip', batch=1, img=(352, 1216), align_corners=False, rescale=True, min_depth=1e-3, max_depth=80.0, seed=0,
@@ -620,16 +675,16 @@ def gen_loopfcn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
-        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost'):       # separate processes: the trees' registries collide
+        for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
     with torch.no_grad():
         {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn,
-         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug, 'dpost': gen_dpost}[args.task]()
+         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug, 'dpost': gen_dpost, 'slide': gen_slide}[args.task]()
 
 
 if __name__ == '__main__':

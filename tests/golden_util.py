@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -70,6 +70,16 @@ def load_aug_case(name):
     assert np.allclose(np.array([fingerprint(t) for t in scores]), z['scores_fp'], rtol=1e-12)
     metas = [dict(img_size=tuple(a['img']), crop_size=tuple(a['img_shape']), flip=a['flip']) for a in cfg['augs']]
     return cfg, scores, metas, torch.from_numpy(z['seg']), torch.from_numpy(z['prob']), torch.from_numpy(z['margin'])
+
+
+def load_slide_case(name):
+    """Sliding-window fixture (reference ``simple_test`` / ``inference`` with test_cfg.mode='slide'): -> (cfg, [window scores
+    (1,K,h,w)] row-major over the grid, seg uint8 (oh,ow), prob (K,oh,ow), margin (oh,ow))."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    scores = [synthetic.make_scores(1, cfg['num_classes'], cfg['h'], cfg['w'], cfg['seed'] * 100 + i) for i in range(cfg['n_windows'])]
+    assert np.allclose(np.array([fingerprint(t) for t in scores]), z['scores_fp'], rtol=1e-12)
+    return cfg, scores, torch.from_numpy(z['seg']), torch.from_numpy(z['prob']), torch.from_numpy(z['margin'])
 
 
 def load_dpost_case(name):

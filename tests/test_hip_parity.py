@@ -358,6 +358,64 @@ def test_aug_epilogue_full_size_and_errors():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', case_names('slide'))
+def test_slide_epilogue_golden(name):
+    """fused sliding-window epilogue (ddp_seg_slide_postprocess) vs the reference's own slide_inference / inference / simple_test:
+    probabilities to rounding, class map identical wherever the reference's top-2 margin is above interpolation / exp noise;
+    the three outputs (class map, probabilities, averaged scores) are consistent with each other."""
+    from golden_util import load_slide_case
+    from ddp_amd.engine import seg_slide_postprocess, slide_windows
+    cfg, scores, seg, prob, margin = load_slide_case(name)
+    ys, xs, crop = slide_windows(cfg['img'], cfg['crop_size'], cfg['stride'])
+    sc = torch.stack(scores).cuda()                                     # (windows, 1, K, h, w)
+    args = (sc, ys, xs, crop, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'])
+    got = seg_slide_postprocess(*args, flip=cfg['flip'], want='seg')[0].cpu()
+    p = seg_slide_postprocess(*args, flip=cfg['flip'], want='prob')[0].cpu()
+    raw = seg_slide_postprocess(*args, flip=None, want='scores')[0].cpu()
+    assert max_rel(p, prob) < 2e-6
+    diff = got != seg
+    assert diff.float().mean() < 1e-3 and not (diff & (margin > 1e-5)).any()
+    un = torch.softmax(raw, dim=0)
+    if cfg['flip']:
+        un = un.flip(dims=(2,) if cfg['flip'] == 'horizontal' else (1,))
+    assert max_rel(un, prob) < 2e-6
+
+
+@pytest.mark.gpu
+def test_slide_epilogue_cityscapes_size_and_errors():
+    """Cityscapes protocol of mmseg (1024 x 2048, crop 512 x 1024, stride 341 x 683 -> 3 x 3 windows, 19 classes, b = 2):
+    equals the oracle's slide_inference; one window covering the whole image == the plain epilogue; bad grids are refused."""
+    from ddp_amd import _lib
+    from ddp_amd.engine import seg_postprocess, seg_slide_postprocess, slide_windows
+    from ddp_amd.utils import synthetic
+    from oracle import ddp_oracle as O
+    img, crop_size, stride = (1024, 2048), (512, 1024), (341, 683)
+    ys, xs, crop = slide_windows(img, crop_size, stride)
+    assert (len(ys), len(xs), crop) == (3, 3, (512, 1024)) and ys[-1] == 512 and xs[-1] == 1024
+    scores = [synthetic.make_scores(2, 19, 128, 256, 900 + i) for i in range(9)]
+    sc = torch.stack(scores).cuda()
+    seg = seg_slide_postprocess(sc, ys, xs, crop, img).cpu()
+    raw = seg_slide_postprocess(sc, ys, xs, crop, img, want='scores').cpu()
+    ref = O.seg_slide_inference(scores, ys, xs, crop, img)
+    assert max_rel(raw, ref) < 2e-6
+    top2 = ref.topk(2, dim=1).values
+    diff = seg.long() != ref.argmax(1)
+    assert diff.float().mean() < 1e-3 and not (diff & ((top2[:, 0] - top2[:, 1]) > 1e-4)).any()
+    one = synthetic.make_scores(1, 19, 16, 24, 5).cuda()
+    a = seg_slide_postprocess(one[None], [0], [0], (64, 96), (64, 96), (61, 90), (70, 101), flip='horizontal')
+    b = seg_postprocess(one, (64, 96), (61, 90), (70, 101), flip='horizontal')
+    assert (a != b).float().mean() < 1e-3
+    with pytest.raises(_lib.DdpError):
+        seg_slide_postprocess(torch.zeros(1, 1, 19, 4, 4), [0], [0], (16, 16), (16, 16))                       # CPU tensor
+    with pytest.raises(_lib.DdpError, match='gap|cover'):
+        seg_slide_postprocess(torch.zeros(2, 1, 19, 4, 4).cuda(), [0], [0, 20], (16, 16), (16, 40))           # columns 16..19 uncovered
+    with pytest.raises(_lib.DdpError, match='more than 3'):
+        seg_slide_postprocess(torch.zeros(5, 1, 19, 4, 4).cuda(), [0], [0, 2, 4, 6, 8], (16, 16), (16, 24))   # stride < crop / 3
+    with pytest.raises(ValueError):
+        seg_slide_postprocess(torch.zeros(3, 1, 19, 4, 4).cuda(), [0], [0, 8], (16, 16), (16, 24))            # 3 score maps for 2 windows
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', case_names('dpost'))
 def test_depth_epilogue_golden(name):
     """fused depth epilogue (ddp_depth_postprocess) vs the reference's own ``model(return_loss=False, **data)`` output

@@ -303,16 +303,23 @@ def test_inference_and_aug_test_post_processing():
         model([img, img_f], [[plain], [flipped]], return_loss=False)
     with pytest.raises(ValueError):
         model([img, img_f], [[plain]], return_loss=False)
+    # every entry looks at test_cfg.mode.  'slide' (encoder_decoder.py:180-227) is built since round 4: on this CPU-only
+    # host each entry must travel into the windowed path and end in the sampler's "no CPU path" error - never silently run
+    # whole-image inference, never NotImplementedError
     model.test_cfg = dict(mode='slide', crop_size=(8, 8), stride=(4, 4))
-    with pytest.raises(NotImplementedError):
-        model.inference(img, [plain], True)
-    # every entry checks the mode - 'slide' must not silently run whole-image inference under aug_test / simple_test
-    with pytest.raises(NotImplementedError, match='slide'):
-        model.aug_test([img, img_f], [[plain], [flipped]])
-    with pytest.raises(NotImplementedError, match='slide'):
+    model.extract_feat = lambda im: [torch.zeros(im.shape[0], 256, im.shape[2] // 4, im.shape[3] // 4)]
+    seen = []
+    orig = model.ddim_sample
+    model.ddim_sample = lambda x, m=None, **k: (seen.append(tuple(x.shape)), orig(x, m, **k))[1]
+    for call in (lambda: model.inference(img, [plain], True), lambda: model.simple_test(img, [plain]),
+                 lambda: model.aug_test([img, img_f], [[plain], [flipped]]), lambda: model.slide_inference(img, [plain], True),
+                 lambda: model([img, img_f], [[plain], [flipped]], return_loss=False)):
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            call()
+    assert seen and all(s[2:] == (2, 2) for s in seen)          # the sampler saw 8 x 8-pixel windows, batched
+    model.test_cfg = dict(mode='tiles')
+    with pytest.raises(AssertionError):
         model.simple_test(img, [plain])
-    with pytest.raises(NotImplementedError, match='slide'):
-        model([img, img_f], [[plain], [flipped]], return_loss=False)
 
 
 def test_full_config_dict_with_a_backbone_entry():

@@ -113,6 +113,24 @@ def test_aug_test_golden(name):
     assert max_rel(p[0], prob) < TOL
 
 
+@pytest.mark.parametrize('name', case_names('slide'))
+def test_slide_inference_golden(name):
+    """sliding-window inference (encoder_decoder.py:180-227), fixtures made by the reference's own simple_test / inference with
+    test_cfg.mode='slide' (backbone and sampler replaced by seeded per-window scores)."""
+    import torch.nn.functional as F
+    from golden_util import load_slide_case
+    from ddp_amd.engine import slide_windows
+    cfg, scores, seg, prob, margin = load_slide_case(name)
+    ys, xs, crop = slide_windows(cfg['img'], cfg['crop_size'], cfg['stride'])
+    assert len(ys) * len(xs) == cfg['n_windows']
+    preds = O.seg_slide_inference(scores, ys, xs, crop, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'])
+    p = F.softmax(preds, dim=1)
+    if cfg['flip']:
+        p = p.flip(dims=(3,) if cfg['flip'] == 'horizontal' else (2,))
+    assert max_rel(p[0], prob) < TOL
+    assert torch.equal(p.argmax(1)[0].to(torch.uint8), seg)
+
+
 @pytest.mark.parametrize('name', case_names('dpost'))
 def test_depth_epilogue_golden(name):
     """depth toolbox test entry (clamp / resize / flip-undo / mean over augmentations), fixtures made by calling the reference

@@ -341,6 +341,59 @@ def test_sample_as_hip_graph_is_bit_identical(case, sampler):
         graph.replay()
 
 
+def test_segmentor_slide_inference_matches_the_reference_composition():
+    """test_cfg.mode='slide' on the drop-in segmentor (encoder_decoder.py:180-227): the windows go through the K-step loop as
+    ONE batch and one fused epilogue; compared with the reference's formulation composed in torch from this class's own
+    per-window ``encode_decode`` with the same noise (the batched call draws the windows' noise as one tensor)."""
+    import numpy as np
+    cfg, sd, x, _, _, _ = load_case('seg_city_r2')
+    model = _seg_model(dict(cfg, randsteps=1))
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    model.test_cfg = dict(mode='slide', crop_size=(32, 48), stride=(20, 30))
+    H, W = 56, 100
+    ys, xs = [0, 20, 24], [0, 30, 52]
+
+    class CropBackbone(torch.nn.Module):               # the "feature" of a crop = a pooled view of the crop itself: depends on its content
+        def forward(self, img):
+            return [torch.nn.functional.avg_pool2d(img, 4).repeat(1, 86, 1, 1)[:, :256].contiguous()]
+    model.backbone = CropBackbone()
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(1, 3, H, W, generator=g).cuda()
+    meta = [dict(img_shape=(H - 2, W - 3, 3), ori_shape=(H + 5, W + 9, 3), flip=True, flip_direction='horizontal')]
+    torch.manual_seed(21)
+    seg = model.simple_test(img, meta, rescale=True)[0]
+    torch.manual_seed(21)
+    preds = model.slide_inference(img, meta, True)
+    assert seg.shape == (H + 5, W + 9) and tuple(preds.shape) == (1, cfg['num_classes'], H + 5, W + 9)
+    # reference composition: the same noise, window by window
+    torch.manual_seed(21)
+    noise = torch.randn((9, 1, 256, 8, 12), device='cuda')
+    acc = torch.zeros(1, cfg['num_classes'], H, W, device='cuda')
+    cnt = torch.zeros(1, 1, H, W, device='cuda')
+    i = 0
+    for y1 in ys:
+        for x1 in xs:
+            crop = img[:, :, y1:y1 + 32, x1:x1 + 48]
+            low = model.ddim_sample(model.extract_feat(crop)[0], noise=noise[i:i + 1])
+            acc[:, :, y1:y1 + 32, x1:x1 + 48] += torch.nn.functional.interpolate(low, size=(32, 48), mode='bilinear', align_corners=False)
+            cnt[:, :, y1:y1 + 32, x1:x1 + 48] += 1
+            i += 1
+    want = torch.nn.functional.interpolate((acc / cnt)[:, :, :H - 2, :W - 3], size=(H + 5, W + 9), mode='bilinear', align_corners=False)
+    assert max_rel(preds.cpu(), want.cpu()) < 1e-5
+    ref = torch.softmax(want, dim=1).flip(dims=(3,)).argmax(1)[0].cpu().numpy()
+    assert (seg != ref).mean() < 2e-3
+    # the harness call and inference() in slide mode; aug_test composes inference()
+    torch.manual_seed(21)
+    assert np.array_equal(model([img], [meta], return_loss=False)[0], seg)
+    torch.manual_seed(21)
+    prob = model.inference(img, meta, True)
+    assert torch.allclose(prob.sum(1), torch.ones_like(prob[:, 0]), atol=1e-5)
+    assert (prob.argmax(1)[0].cpu().numpy() != seg).mean() < 1e-3
+    out = model([img, img], [meta, [dict(meta[0], flip=False)]], return_loss=False)
+    assert out[0].shape == (H + 5, W + 9)
+
+
 def test_engine_set_geometry_is_transactional():
     """a geometry switch that fails (here: more tokens than the library accepts) must leave the engine on its old,
     still prepared geometry - the same bad request fails again instead of hitting the early-return, and the next good call
