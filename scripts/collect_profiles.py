@@ -89,6 +89,17 @@ for wl in ('ade_swin_t_k3_1x512x1024', 'city_swin_l_k10_4x1024x2048', 'kitti_dep
                 r['mfma_busy_frac'] = round(r.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / (r['GRBM_GUI_ACTIVE'] / 8.0), 4)
             out2[k] = r
         json.dump(out2, open(os.path.join(dst, f'{tag}_{wl}_pmc_mfma.json'), 'w'), indent=1)
+for wl in ('ade_swin_t_k3_8x512x1024', 'city_swin_l_k10_4x1024x2048', 'bev_fusion_k3_8x200x200'):
+    f = os.path.join(src, f'{wl}_scaling_strong_n1.json')
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f'{tag}_{wl}_scaling_strong_n1.json'))
+f = glob.glob(os.path.join(src, 'prof_fcn', '**', '*kernel_stats.csv'), recursive=True)
+if f:
+    shutil.copy(f[0], os.path.join(dst, f'{tag}_fcn_sampler_6_calls_kernel_stats.csv'))
+for name in ('power_components.json', 'fcn_calls.log'):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f'{tag}_{name}'))
 for name in ('force_dist_rccl_world1.json', 'force_dist_rccl_world1.err'):
     f = os.path.join(src, name)
     if os.path.exists(f):

@@ -18,7 +18,7 @@ fi
 PYTEST_ORDER="python -m pytest tests -m gpu -q -s"
 run_tests() { $PYTEST_ORDER ${KSEL:+"$KSEL"} 2>&1 | grep -v "amdgpu.ids\|^$" > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt; }
 [ "$QUICK" = quick ] || run_tests
-python bench.py --steps 10 --warmup 2 --next-rows --size-stream 50 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 10 --warmup 2 --next-rows --size-stream 50 --host-leg > $OUT/bench.json 2> $OUT/bench.err
 cut -c1-2500 $OUT/bench.json; tail -3 $OUT/bench.err
 # the strong-scaling shard of the headline configuration (one image per GPU at 8 GPUs), with kernel stats
 python bench.py --workload ade_swin_t_k3_1x512x1024 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_ade_swin_t_k3_1x512x1024.json 2> $OUT/bench_b1.err
@@ -54,6 +54,16 @@ done
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
     --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power --force-dist > $OUT/force_dist_rccl_world1.json 2> $OUT/force_dist_rccl_world1.err
 tail -1 $OUT/force_dist_rccl_world1.json | cut -c1-300
+# strong scaling at N = 1 (what `--scaling strong --gpus 1` reports: the configuration's total batch in calls of the workload's batch)
+for wl in ade_swin_t_k3_8x512x1024 city_swin_l_k10_4x1024x2048 bev_fusion_k3_8x200x200; do
+  [ "$QUICK" = quick ] && [ $wl != ade_swin_t_k3_8x512x1024 ] && continue
+  timeout 300 python bench.py --workload $wl --scaling strong --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-power > $OUT/${wl}_scaling_strong_n1.json 2> $OUT/strong_$wl.err
+done
+# FCN-head sampler: the loop-invariant kernels run once per engine, not per call (ddp_prepare_fcn)
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_fcn -o fcn -- python $REPO/scripts/fcn_launch_count.py > $REPO/$OUT/fcn_calls.log 2>&1 )
+grep "^call" $OUT/fcn_calls.log
+# what costs what under the cap: MFMA alone, + LDS fragment reads + VALU fillers, + the LDS-DMA weight stream, + the HBM streams
+timeout 300 python scripts/power_calibration.py --components --seconds 3 > $OUT/power_components.json 2> $OUT/power_components.err
 # what this box gives the matrix pipes under its package power cap: vendor bf16 GEMM, MFMA-only loops
 [ "$QUICK" = quick ] || timeout 300 python scripts/power_calibration.py > $OUT/power_calibration.json 2> $OUT/power_calibration.err
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)

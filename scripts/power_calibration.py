@@ -155,7 +155,8 @@ def main():
     print('headline', json.dumps(res['headline']), file=sys.stderr, flush=True)
     if args.components:
         legs = [('mfma_only', (0, 0, 0, 0)), ('mix', (1, 3, 0, 0)), ('mfma+dma', (0, 0, 1, 0)), ('mix+dma', (1, 3, 1, 0)),
-                ('mix+hbm', (1, 3, 0, 1)), ('mix+dma+hbm', (1, 3, 1, 1)), ('mix (again)', (1, 3, 0, 0))]
+                ('mix+dma+hbm', (1, 3, 1, 1)), ('mix (again)', (1, 3, 0, 0))]
+        # (the leg "mix + HBM streams without the weight stream" faults on the box - r04b / r04c, cause not found - and is left out)
         res['components'] = []
         for name, (l, v, d, hb) in legs:
             rec = mfma_chip(1, 2, 1, args.seconds, l, v, d, hb)
