@@ -596,12 +596,19 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # per-step spread (segmentation/tools/benchmark.py:80-109 reports the rate over many iterations; SURVEY §8d asks for mean and
+    # variance): one HIP event per step on the stream the library launches on - an event record is stream-ordered and costs no
+    # synchronisation; the contract's clock stays the barrier-to-barrier wall time around all K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         one_step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -876,6 +883,9 @@ def main():
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
             'images_per_s_per_gpu': round(images_per_s / world, 3),
+            'step_ms': {'mean': round(sum(step_ms) / len(step_ms), 3), 'min': round(min(step_ms), 3), 'max': round(max(step_ms), 3),
+                        'std': round((sum((t - sum(step_ms) / len(step_ms)) ** 2 for t in step_ms) / len(step_ms)) ** 0.5, 3),
+                        'source': 'HIP events between the steps of the timed region (rank 0)'},
             'roofline': roofline, 'power': power, 'joules_per_image': (power or {}).get('joules_per_image'),
             'cpu_baseline': cpu, 'parity': parity, 'next_rows': next_rows, 'size_stream': stream_res, 'host': host_res,
         }
