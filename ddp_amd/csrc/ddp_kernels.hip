@@ -927,11 +927,15 @@ __global__ void __launch_bounds__(256) k_seg_postprocess_x4(SegPostArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Test-time-augmentation epilogue (encoder_decoder.py:306-331 aug_test), fused.  One wave = 64 output pixels; per pixel and
-// augmentation: the two-stage bilinear resize of k_seg_postprocess for every class (values parked in LDS), softmax over the
-// classes, accumulation into the pixel's running sum (LDS), flip undone by reading the mirrored source pixel; after the last
-// augmentation: / n_aug, argmax (first maximum wins), optional store of the mean probabilities.
-// LDS: 2 x K x 64 floats (tmp | acc), column = thread -> conflict-free.
+// Test-time-augmentation epilogue (encoder_decoder.py:306-331 aug_test), fused.  A block = 64 output pixels of one row x 4
+// waves; every wave walks the SAME 64 pixels and a quarter of the classes (the class-independent index arithmetic is repeated
+// per wave: ~7 % of the work at 150 classes).  Per pixel and augmentation: the two-stage bilinear resize of k_seg_postprocess
+// for the wave's classes (values parked in LDS), softmax over ALL classes (per-wave maximum / sum combined through LDS in a
+// fixed order), accumulation into the pixel's running sum (LDS), flip undone by reading the mirrored source pixel; after the
+// last augmentation: / n_aug, argmax (first maximum wins), optional store of the mean probabilities.
+// LDS: 2 x K x 64 floats (tmp | acc, column = thread -> conflict-free) + 2 x 4 x 64 for the reductions.  (Until round 4 a block
+// was ONE wave walking all classes: 77 KB of LDS per wave at 150 classes = 2 waves per CU, latency bound - 5.5 ms for the ADE
+// multi-scale + flip case of scripts/epilogue_times.py.)
 // ------------------------------------------------------------------------------------------------
 struct SegAugArgs {
   ddp_seg_aug aug[DDP_MAX_AUGS];
@@ -939,16 +943,20 @@ struct SegAugArgs {
   unsigned char* seg;
   float* prob;      // optional (B,K,oh,ow)
 };
-__global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
+__global__ void __launch_bounds__(256) k_seg_aug_postprocess(SegAugArgs a) {
   extern __shared__ float aug_lds[];
   float* tmp = aug_lds;
   float* acc = aug_lds + size_t(a.K) * 64;
-  const int tid = threadIdx.x;
+  float* red = aug_lds + size_t(a.K) * 128;                 // [2][4][64]: per-wave maxima | per-wave sums (then: best value | class)
+  const int tid = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int x = blockIdx.x * 64 + tid;
   const int y = blockIdx.y;
   const int b = blockIdx.z;
   const bool live = x < a.ow;
-  const int xs = live ? x : a.ow - 1;
+  const int xs = live ? x : a.ow - 1;                        // (threads past the row's end compute a copy: they take part in the barriers)
+  const int kq = (a.K + 3) >> 2;
+  const int c0 = wv * kq, c1 = min(a.K, c0 + kq);            // this wave's classes
   for (int i = 0; i < a.n_aug; ++i) {
     const ddp_seg_aug& g = a.aug[i];
     const int sx = g.flip == 1 ? a.ow - 1 - xs : xs;
@@ -959,9 +967,9 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
     const UpIdx ya = up_index(Y.i0, g.h, g.img_h, a.align), yb = up_index(Y.i1, g.h, g.img_h, a.align);
     const UpIdx xa = up_index(X.i0, g.w, g.img_w, a.align), xb = up_index(X.i1, g.w, g.img_w, a.align);
     const size_t ps = size_t(g.h) * g.w;
-    const float* plane = g.d_scores + size_t(b) * a.K * ps;
+    const float* plane = g.d_scores + (size_t(b) * a.K + c0) * ps;
     float mx = -INFINITY;
-    for (int c = 0; c < a.K; ++c, plane += ps) {
+    for (int c = c0; c < c1; ++c, plane += ps) {
       const float* r0 = plane + size_t(ya.i0) * g.w;
       const float* r1 = plane + size_t(ya.i1) * g.w;
       float v = bilerp(r0[xa.i0], r0[xa.i1], r1[xa.i0], r1[xa.i1], ya, xa);
@@ -976,23 +984,29 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
       tmp[c * 64 + tid] = v;
       mx = fmaxf(mx, v);
     }
+    red[wv * 64 + tid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[tid], red[64 + tid]), fmaxf(red[128 + tid], red[192 + tid]));
     float sum = 0.f;
-    for (int c = 0; c < a.K; ++c) {
+    for (int c = c0; c < c1; ++c) {
       const float e = expf(tmp[c * 64 + tid] - mx);
       tmp[c * 64 + tid] = e;
       sum += e;
     }
-    for (int c = 0; c < a.K; ++c) {
+    red[256 + wv * 64 + tid] = sum;
+    __syncthreads();                                         // (the next write of red[0..255] is behind this barrier: all maxima are read)
+    sum = ((red[256 + tid] + red[320 + tid]) + red[384 + tid]) + red[448 + tid];
+    for (int c = c0; c < c1; ++c) {
       const float p = tmp[c * 64 + tid] / sum;
       acc[c * 64 + tid] = i == 0 ? p : acc[c * 64 + tid] + p;
     }
+    // (the next write of red[256..511] is behind the NEXT augmentation's first barrier: all sums are read by then)
   }
-  if (!live) return;
   const float nf = float(a.n_aug);
   float best = -INFINITY;
-  int arg = 0;
-  float* pout = a.prob ? a.prob + (size_t(b) * a.K * a.oh + y) * a.ow + x : nullptr;
-  for (int c = 0; c < a.K; ++c) {
+  int arg = 0x7fffffff;
+  float* pout = (a.prob && live) ? a.prob + (size_t(b) * a.K * a.oh + y) * a.ow + x : nullptr;
+  for (int c = c0; c < c1; ++c) {
     const float p = acc[c * 64 + tid] / nf;
     if (pout) pout[size_t(c) * a.oh * a.ow] = p;
     if (p > best) {
@@ -1000,7 +1014,21 @@ __global__ void __launch_bounds__(64) k_seg_aug_postprocess(SegAugArgs a) {
       arg = c;
     }
   }
-  a.seg[(size_t(b) * a.oh + y) * a.ow + x] = (unsigned char)arg;
+  __syncthreads();                                           // the sums of the last augmentation are read: red is free
+  red[wv * 64 + tid] = best;
+  red[256 + wv * 64 + tid] = __int_as_float(arg);
+  __syncthreads();
+  if (wv == 0 && live) {
+    // first maximum wins: the waves hold ascending class ranges, a strict '>' keeps the lower class on ties
+    for (int q = 1; q < 4; ++q) {
+      const float ob = red[q * 64 + tid];
+      if (ob > best) {
+        best = ob;
+        arg = __float_as_int(red[256 + q * 64 + tid]);
+      }
+    }
+    a.seg[(size_t(b) * a.oh + y) * a.ow + x] = (unsigned char)(arg == 0x7fffffff ? 0 : arg);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1848,11 +1876,11 @@ int launch_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int B, int K,
   a.align = align;
   a.seg = seg;
   a.prob = prob;
-  const int lds = 2 * K * 64 * int(sizeof(float));
-  // the attribute is set once per device: ask for the largest size the API accepts (K = 256: 128 KiB), not this call's
+  const int lds = (2 * K * 64 + 512) * int(sizeof(float));
+  // the attribute is set once per device: ask for the largest size the API accepts (K = 256: 130 KiB), not this call's
   static LdsAttrOnce attr;
-  attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), 2 * 256 * 64 * int(sizeof(float)));
-  hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(64), lds, st, a);
+  attr.ensure(reinterpret_cast<const void*>(k_seg_aug_postprocess), (2 * 256 * 64 + 512) * int(sizeof(float)));
+  hipLaunchKernelGGL(k_seg_aug_postprocess, dim3(cdiv(ow, 64), oh, B), dim3(256), lds, st, a);
   return check_launch("k_seg_aug_postprocess");
 }
 int launch_seg_slide_postprocess(const float* const* scores, const int* y1, const int* x1, int n_rows, int n_cols, int B, int K, int h,
