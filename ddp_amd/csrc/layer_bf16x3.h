@@ -686,15 +686,25 @@ k_layer(LayerArgs la) {
       }
       const float* abase = la.gp[pi].A;
       const float* arow = abase + grp5 * size_t(ns) * 1024 + lane * 4;      // plain: this wave's group, 32 * ns channels
+      // 3x3 view: the shifted token's address and its border verdict change with the TAP, i.e. every eighth stage - they are
+      // carried across the eight channel blocks of a tap (round 4: re-deriving tap (a division by 3), shifted token, four
+      // border comparisons and a 64-bit address in front of EVERY stage put ~60 scalar + 25 vector instructions before the
+      // stage's first MFMA; at one wave per SIMD all of them exposed)
+      const float* tap_ptr = abase;
+      bool tap_ok = false;
       auto a_load = [&](int st, f32x4 (&dst)[4]) __attribute__((always_inline)) {
         const float* ap = arow + size_t(st) * 1024;
         bool ok = true;
         if (ch > 0) {
-          const int tap = st >> 3;
-          const int dy = (tap / 3 - 1) * la.conv_dil, dx = (tap - (tap / 3) * 3 - 1) * la.conv_dil;
-          ok = mvalid && ci + dy >= 0 && ci + dy < ch && cj + dx >= 0 && cj + dx < cw;
-          const int ms = ok ? m + dy * cw + dx : 0;
-          ap = abase + size_t(ms >> 5) * 8192 + size_t(st & 7) * 1024 + (h * 32 + (ms & 31)) * 4;
+          if ((st & 7) == 0) {                                     // (uniform: a scalar branch)
+            const int tap = st >> 3;
+            const int dy = (tap / 3 - 1) * la.conv_dil, dx = (tap - (tap / 3) * 3 - 1) * la.conv_dil;
+            tap_ok = mvalid && ci + dy >= 0 && ci + dy < ch && cj + dx >= 0 && cj + dx < cw;
+            const int ms = tap_ok ? m + dy * cw + dx : 0;
+            tap_ptr = abase + size_t(ms >> 5) * 8192 + (h * 32 + (ms & 31)) * 4;
+          }
+          ok = tap_ok;
+          ap = tap_ptr + size_t(st & 7) * 1024;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
