@@ -1671,6 +1671,42 @@ __global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__
   }
 }
 
+// The same reduction + transpose for maps whose token count is a multiple of 4 (every BASELINE configuration): a block moves a
+// tile of 256 tokens x 32 classes.  Reads: 8 lanes per token row fetch its 128-B class segment (one cache line: ldl % 32 == 0),
+// 32 rows per pass; writes: per class a wave stores 256 consecutive tokens as ONE 1-KiB instruction.  (k_finalize_nchw above
+// writes 256-B pieces to K different planes per block and divides by a run-time K per element: 2.6 TB/s at C2.)
+constexpr int FIN_T = 256, FIN_K = 32, FIN_LD = FIN_T + 4;
+__global__ void __launch_bounds__(256) k_finalize_nchw_t(const float* __restrict__ prob, int ldl, float* __restrict__ out, int r, int N,
+                                                          int K, float div) {
+  __shared__ float tile[FIN_K][FIN_LD];
+  const int b = blockIdx.z;
+  const int k0 = blockIdx.y * FIN_K;
+  const int n0 = blockIdx.x * FIN_T;
+  const int tt = threadIdx.x >> 3, q = threadIdx.x & 7;        // row of the pass, 4-class group of the segment
+#pragma unroll
+  for (int pass = 0; pass < FIN_T / 32; ++pass) {
+    const int n = n0 + pass * 32 + tt;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      for (int ri = 0; ri < r; ++ri) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(prob + (size_t(b * r + ri) * N + n) * ldl + k0 + 4 * q);
+        s = ri == 0 ? v : s + v;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[4 * q + e][pass * 32 + tt] = s[e] / div;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = n0 + 4 * lane;
+  if (n >= N) return;
+  for (int kk = wv; kk < FIN_K; kk += 4) {
+    const int k = k0 + kk;
+    if (k >= K) break;
+    *reinterpret_cast<f32x4*>(out + (size_t(b) * K + k) * N + n) = *reinterpret_cast<const f32x4*>(&tile[kk][4 * lane]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // depth (depth/depth/models/depther/ddp.py:220-247; decode_heads/decode_head.py:264-269)
 // ------------------------------------------------------------------------------------------------
@@ -2056,6 +2092,10 @@ int launch_seg_x0_nchw(const float* scores, const float* emb, float* out, int B,
 }
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
                          hipStream_t st) {
+  if (N % 4 == 0 && ldl % 32 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(k_finalize_nchw_t, dim3(cdiv(N, FIN_T), cdiv(K, FIN_K), B), dim3(256), 0, st, prob, ldl, out, r, N, K, div);
+    return check_launch("k_finalize_nchw_t");
+  }
   const size_t lds = size_t(64) * (K + 1) * sizeof(float);
   static LdsAttrOnce attr;
   attr.ensure(reinterpret_cast<const void*>(&k_finalize_nchw), 64 * 257 * int(sizeof(float)));
