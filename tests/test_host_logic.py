@@ -154,6 +154,36 @@ def test_depther_has_the_toolbox_test_entry():
         m(return_loss=False, img=[img], img_metas=[[meta]])
 
 
+def test_slide_window_grid_matches_the_reference_loop():
+    """``ddp_amd.engine.slide_windows`` against the loop of ``slide_inference`` (encoder_decoder.py:186-206) written out: same
+    clamped origins in the same (row-major) order, every pixel covered, windows inside the image - for random sizes, crops larger
+    than the image included."""
+    import random
+    from ddp_amd.engine import slide_windows
+    rnd = random.Random(7)
+    for _ in range(300):
+        H, W = rnd.randint(8, 300), rnd.randint(8, 300)
+        hc, wc = rnd.randint(8, 200), rnd.randint(8, 200)
+        hs, ws = rnd.randint(max(1, hc // 3), hc), rnd.randint(max(1, wc // 3), wc)
+        h_grids = max(H - hc + hs - 1, 0) // hs + 1
+        w_grids = max(W - wc + ws - 1, 0) // ws + 1
+        want = []
+        for hi in range(h_grids):
+            for wi in range(w_grids):
+                y1, x1 = hi * hs, wi * ws
+                y2, x2 = min(y1 + hc, H), min(x1 + wc, W)
+                y1, x1 = max(y2 - hc, 0), max(x2 - wc, 0)
+                want.append((y1, x1, y2, x2))
+        ys, xs, (ch, cw) = slide_windows((H, W), (hc, wc), (hs, ws))
+        got = [(y, x, y + ch, x + cw) for y in ys for x in xs]
+        assert got == want, (H, W, hc, wc, hs, ws)
+        cover = torch.zeros(H, W, dtype=torch.int32)
+        for y1, x1, y2, x2 in got:
+            assert 0 <= y1 < y2 <= H and 0 <= x1 < x2 <= W
+            cover[y1:y2, x1:x2] += 1
+        assert int(cover.min()) >= 1
+
+
 def test_depth_and_bev_state_dict_layout():
     cfg = dict(type='DDP', sample_range=(0., 0.999), bit_scale=0.1, timesteps=3, min_depth=1e-3, max_depth=80,
                decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
