@@ -122,7 +122,11 @@ class DDP(nn.Module, _SamplerMixin):
 
     def _post(self, maps, flips, size):
         from ..engine import depth_postprocess
-        return depth_postprocess(maps, flips, size, self.decode_head.min_depth, self.decode_head.max_depth, self.align_corners)
+        # torch.clamp(out, min=head.min_depth, max=head.max_depth) (depther/ddp.py:101): a head built without max_depth does not
+        # clamp from above
+        lo = self.decode_head.min_depth if self.decode_head.min_depth is not None else float('-inf')
+        hi = self.decode_head.max_depth if self.decode_head.max_depth is not None else float('inf')
+        return depth_postprocess(maps, flips, size, lo, hi, self.align_corners)
 
     def encode_decode(self, img, img_metas=None, rescale=False):
         """depther/ddp.py:95-109: clamp to the head's depth range, resize to the network input when ``rescale`` - one fused
