@@ -394,6 +394,64 @@ def test_segmentor_slide_inference_matches_the_reference_composition():
     assert out[0].shape == (H + 5, W + 9)
 
 
+def _seg_model_for_epilogue(num_classes, align_corners, test_cfg=None):
+    from ddp_amd.utils import synthetic
+    cfg = seg_cfg(decode_head=dict(seg_cfg()['decode_head'], num_classes=num_classes, align_corners=align_corners), test_cfg=test_cfg)
+    model = ddp_amd.build_segmentor(cfg)
+    model.load_state_dict(synthetic.make_state_dict('seg', num_classes, 6, 256, seed=0), strict=True)
+    model = model.cuda().eval()
+    model.extract_feat = lambda img: [torch.zeros(img.shape[0], 256, 1, 1, device='cuda')]
+    return model
+
+
+def _same_class_map(got, seg, margin):
+    diff = torch.from_numpy(got.astype('int64')) != seg.long()
+    return float(diff.float().mean()) < 1e-3 and not bool((diff & (margin > 1e-5)).any())
+
+
+def test_segmentor_harness_call_matches_reference_fixtures():
+    """The segmentation harness call ``model(return_loss=False, **data)`` (segmentation/mmseg/apis/test.py:87-89) on the drop-in class
+    against what the REFERENCE model returned for it, for the three post-loop protocols: single scale (`post_*`, simple_test),
+    multi-scale / flip (`aug_*`, aug_test) and sliding window (`slide_*`, test_cfg.mode='slide') - backbone and sampler replaced
+    by the same seeded low-resolution scores on both sides (the plugin's epilogue path compared with the
+    reference, not with its own torch composition)."""
+    from golden_util import case_names, load_aug_case, load_post_case, load_slide_case
+    for name in case_names('post'):
+        cfg, scores, seg, margin = load_post_case(name)
+        model = _seg_model_for_epilogue(cfg['num_classes'], cfg['align_corners'], dict(mode='whole'))
+        model.ddim_sample = lambda x, img_metas=None, _s=scores: _s.cuda()
+        meta = dict(img_shape=tuple(cfg['img_shape']) + (3,), ori_shape=tuple(cfg['ori_shape']) + (3,), pad_shape=tuple(cfg['img']) + (3,),
+                    flip=cfg['flip'] is not None, flip_direction=cfg['flip'] or 'horizontal')
+        res = model(return_loss=False, img=[torch.zeros((1, 3) + tuple(cfg['img']), device='cuda')], img_metas=[[meta]])
+        assert len(res) == 1 and res[0].shape == tuple(cfg['ori_shape']) and _same_class_map(res[0], seg, margin), name
+    for name in case_names('aug'):
+        cfg, scores, metas, seg, prob, margin = load_aug_case(name)
+        model = _seg_model_for_epilogue(cfg['num_classes'], cfg['align_corners'], dict(mode='whole'))
+        calls = []
+
+        def sample(x, img_metas=None, _c=calls, _s=scores):
+            _c.append(1)
+            return _s[(len(_c) - 1) % len(_s)].cuda()
+        model.ddim_sample = sample
+        imgs = [torch.zeros((1, 3) + tuple(a['img']), device='cuda') for a in cfg['augs']]
+        mm = [[dict(img_shape=tuple(a['img_shape']) + (3,), ori_shape=tuple(cfg['ori_shape']) + (3,), pad_shape=tuple(a['img']) + (3,),
+                    flip=a['flip'] is not None, flip_direction=a['flip'] or 'horizontal')] for a in cfg['augs']]
+        res = model(return_loss=False, img=imgs, img_metas=mm)
+        assert len(calls) == len(imgs) and res[0].shape == tuple(cfg['ori_shape']) and _same_class_map(res[0], seg, margin), name
+    for name in case_names('slide'):
+        cfg, scores, seg, prob, margin = load_slide_case(name)
+        model = _seg_model_for_epilogue(cfg['num_classes'], cfg['align_corners'],
+                                        dict(mode='slide', crop_size=tuple(cfg['crop_size']), stride=tuple(cfg['stride'])))
+        model.extract_feat = lambda img: [torch.zeros(img.shape[0], 256, cfg['h'], cfg['w'], device='cuda')]
+        model.ddim_sample = lambda x, img_metas=None, _s=scores: torch.cat(_s).cuda()       # the windows arrive as ONE batch
+        meta = dict(img_shape=tuple(cfg['img_shape']) + (3,), ori_shape=tuple(cfg['ori_shape']) + (3,), pad_shape=tuple(cfg['img']) + (3,),
+                    flip=cfg['flip'] is not None, flip_direction=cfg['flip'] or 'horizontal')
+        res = model(return_loss=False, img=[torch.zeros((1, 3) + tuple(cfg['img']), device='cuda')], img_metas=[[meta]])
+        assert res[0].shape == tuple(cfg['ori_shape']) and _same_class_map(res[0], seg, margin), name
+        p = model.inference(torch.zeros((1, 3) + tuple(cfg['img']), device='cuda'), [meta], True)
+        assert max_rel(p[0].cpu(), prob) < 2e-6, name
+
+
 def test_engine_set_geometry_is_transactional():
     """a geometry switch that fails (here: more tokens than the library accepts) must leave the engine on its old,
     still prepared geometry - the same bad request fails again instead of hitting the early-return, and the next good call
