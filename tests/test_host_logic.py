@@ -184,6 +184,37 @@ def test_slide_window_grid_matches_the_reference_loop():
         assert int(cover.min()) >= 1
 
 
+def test_dependency_cone_of_flipped_decisions():
+    """The localisation assertion of the full-size parity tests (tests/test_full_size_parity.py::_dependency_cone): a decision that
+    differs at step s changes the noisy map entering the LATER steps at that pixel only (the update and the concat-conv are
+    pointwise, segmentors/ddp.py:223-239) and one decoder pass spreads a changed input by at most `reach` pixels."""
+    import test_full_size_parity as T
+    h, w, K, reach = 40, 60, 4, 5
+    none = [torch.zeros(h, w, dtype=torch.bool) for _ in range(K)]
+    assert not T._dependency_cone(none, reach, False).any() and not T._dependency_cone(none, reach, True).any()
+
+    def flip_at(step, y, x):
+        d = [m.clone() for m in none]
+        d[step][y, x] = True
+        return d
+    box = torch.zeros(h, w, dtype=torch.bool)
+    box[20 - reach:20 + reach + 1, 30 - reach:30 + reach + 1] = True
+    for step in range(K - 1):                                   # any step before the last reaches the last step's scores
+        assert torch.equal(T._dependency_cone(flip_at(step, 20, 30), reach, False), box)
+        assert torch.equal(T._dependency_cone(flip_at(step, 20, 30), reach, True), box)
+    # a decision of the LAST step feeds nothing back into the output (the sampler returns that step's scores / their mean)
+    assert not T._dependency_cone(flip_at(K - 1, 20, 30), reach, False).any()
+    assert not T._dependency_cone(flip_at(K - 1, 20, 30), reach, True).any()
+    # the image border clips the box; two flips give the union
+    c = T._dependency_cone(flip_at(0, 0, 0), reach, False)
+    assert int(c.sum()) == (reach + 1) ** 2 and bool(c[reach, reach]) and not bool(c[reach + 1, 0])
+    d = flip_at(1, 20, 30)
+    d[2][5, 50] = True
+    u = T._dependency_cone(d, reach, True)
+    assert bool(u[20, 30]) and bool(u[5, 50]) and int(u.sum()) == 2 * (2 * reach + 1) ** 2
+    assert torch.equal(T._dilate(none[0], 3), none[0])
+
+
 def test_depth_and_bev_state_dict_layout():
     cfg = dict(type='DDP', sample_range=(0., 0.999), bit_scale=0.1, timesteps=3, min_depth=1e-3, max_depth=80,
                decode_head=dict(type='DeformableHeadWithTime', in_channels=[256], channels=256, in_index=[0],
