@@ -49,6 +49,8 @@ class DDP(nn.Module, _SamplerMixin):
             raise ValueError(f'invalid noise schedule {noise_schedule}')
         if tmp_channels != 256:
             raise ValueError('libddp_mi355x is built for tmp_channels=256')
+        if learned_sinusoidal_dim != 16:
+            raise ValueError('libddp_mi355x is built for learned_sinusoidal_dim=16')
         self.bit_scale, self.timesteps, self.randsteps = bit_scale, timesteps, randsteps
         self.diffusion, self.time_difference, self.sample_range = diffusion, time_difference, sample_range
         self.noise_schedule = noise_schedule

@@ -150,7 +150,8 @@ int validate(const ddp_cfg* c) {
     set_error("bev supports at most 32 classes");
     return DDP_E_BADCFG;
   }
-  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO)) {
+  if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO |
+                   DDP_FLAG_FORCE_X0)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -276,7 +277,9 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   o->prob = cv.take(o->M * o->ldl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
   o->x0_trace = reinterpret_cast<unsigned char*>(
-      cv.take((c->flags & DDP_FLAG_RECORD_X0) && c->task == DDP_TASK_SEG ? (size_t(o->K) * o->M + 3) / 4 : 0));
+      cv.take((c->flags & (DDP_FLAG_RECORD_X0 | DDP_FLAG_FORCE_X0)) && c->task == DDP_TASK_SEG
+                  ? ((c->flags & DDP_FLAG_FORCE_X0 ? 2 : 1) * size_t(o->K) * o->M + 3) / 4
+                  : 0));
   if (o->b3) {
     auto takesb = [&](size_t rows, size_t C) {       // SB: 6 bytes per element, rows padded to 256
       const size_t rp = (rows + 255) / 256 * 256;
@@ -868,7 +871,11 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         tl.n_tok = o.Nh;
         tl.w = o.wh;
       }
-      tl.x0_idx = (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
+      // FORCE_X0: [0] = the caller's decisions (read), [1] = the step's own argmax (written); RECORD_X0 alone: [0] written
+      tl.x0_force = (cfg->flags & DDP_FLAG_FORCE_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
+      tl.x0_idx = (cfg->flags & DDP_FLAG_FORCE_X0)   ? o.x0_trace + size_t(o.K + s) * o.M
+                  : (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M
+                                                      : nullptr;
       tl.M = M;
       tl.num_classes = o.Kc;
       tl.ldl = o.ldl;
@@ -893,7 +900,11 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       a.prob = o.prob;
       a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
       a.step_noise = nullptr;
-      a.x0_idx = (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
+      // FORCE_X0: [0] = the caller's decisions (read), [1] = the step's own argmax (written); RECORD_X0 alone: [0] written
+      a.x0_force = (cfg->flags & DDP_FLAG_FORCE_X0) ? o.x0_trace + size_t(s) * o.M : nullptr;
+      a.x0_idx = (cfg->flags & DDP_FLAG_FORCE_X0)   ? o.x0_trace + size_t(o.K + s) * o.M
+                  : (cfg->flags & DDP_FLAG_RECORD_X0) ? o.x0_trace + size_t(s) * o.M
+                                                      : nullptr;
       a.sampler = cfg->sampler;
       a.st = sp;
       a.rows = M;
@@ -958,8 +969,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
 int ddp_x0_trace(const ddp_cfg* cfg, void* d_workspace, const unsigned char** d_idx) {
   DDP_TRY(validate(cfg));
   DDP_TRY(check_ptr(d_workspace, "workspace"));
-  if (!d_idx || !(cfg->flags & DDP_FLAG_RECORD_X0) || cfg->task != DDP_TASK_SEG) {
-    set_error("x0_trace: needs a segmentation cfg with DDP_FLAG_RECORD_X0");
+  if (!d_idx || !(cfg->flags & (DDP_FLAG_RECORD_X0 | DDP_FLAG_FORCE_X0)) || cfg->task != DDP_TASK_SEG) {
+    set_error("x0_trace: needs a segmentation cfg with DDP_FLAG_RECORD_X0 or DDP_FLAG_FORCE_X0");
     return DDP_E_BADCFG;
   }
   Layout o;
@@ -1221,6 +1232,7 @@ int ddp_ddim_update_seg(const float* d_logits, int ld_logits, int num_classes, c
   a.prob_mode = 0;
   a.step_noise = nullptr;
   a.x0_idx = nullptr;
+    a.x0_force = nullptr;
   a.sampler = DDP_SAMPLER_DDIM;
   a.st = *step;
   a.rows = rows;
@@ -2036,6 +2048,7 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
     a.prob_mode = cfg->accumulation ? (s == 0 ? 1 : 2) : 0;
     a.step_noise = nullptr;
     a.x0_idx = nullptr;
+    a.x0_force = nullptr;
     a.sampler = cfg->sampler;
     a.st = sp;
     a.rows = M;

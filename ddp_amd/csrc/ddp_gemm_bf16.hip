@@ -176,14 +176,19 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   return check_launch("b3::k_layer");
 }
 namespace {
-template <int MODE, int NCH>
-int launch_tail_t(const b3::LayerArgs& la, int grid, hipStream_t st) {
+template <int MODE, int NCH, bool FORCE>
+int launch_tail_tf(const b3::LayerArgs& la, int grid, hipStream_t st) {
   static LdsAttrOnce attr;
-  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, MODE, NCH>), int(b3::LYR_LDS_B));
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_HEAD, MODE, NCH, false, FORCE>), int(b3::LYR_LDS_B));
   prof_begin(TAG_HEAD, st);
-  hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, MODE, NCH>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  hipLaunchKernelGGL((b3::k_layer<TAG_HEAD, MODE, NCH, false, FORCE>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
   prof_end(TAG_HEAD, st);
   return check_launch(MODE == 4 ? "b3::k_layer (seg tail + next step head)" : "b3::k_layer (seg tail)");
+}
+// la.x0_force (DDP_FLAG_FORCE_X0, a test instrument) selects the teacher-forcing instantiation; the product path runs <.., false>
+template <int MODE, int NCH>
+int launch_tail_t(const b3::LayerArgs& la, int grid, hipStream_t st) {
+  return la.x0_force ? launch_tail_tf<MODE, NCH, true>(la, grid, st) : launch_tail_tf<MODE, NCH, false>(la, grid, st);
 }
 }  // namespace
 
@@ -199,6 +204,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
   la.prob = a.prob;
   la.mask_sb = a.mask_sb;
   la.x0_idx = a.x0_idx;
+  la.x0_force = a.x0_force;
   la.num_classes = a.num_classes;
   la.ldl = a.ldl;
   la.prob_mode = a.prob_mode;

@@ -122,6 +122,7 @@ struct TailLaunch {
   float* prob;
   unsigned short* mask_sb;
   unsigned char* x0_idx;        // optional: argmax class per token (diagnostic trace)
+  const unsigned char* x0_force;  // optional (DDP_FLAG_FORCE_X0): the class to feed back instead of the argmax
   int M, num_classes, ldl, prob_mode;
   float alpha, sigma, alpha_next, sigma_next;
   // fuse_next: this launch is also the head of the NEXT step (k_layer MODE 4): mask_sb = nullptr, the update runs on
@@ -235,6 +236,7 @@ struct SegUpdateArgs {
   int prob_mode;        // 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = logits
   const float* step_noise;  // ddpm (M,256) token-major or nullptr
   unsigned char* x0_idx;    // optional: argmax class per token (diagnostic trace)
+  const unsigned char* x0_force;  // optional (DDP_FLAG_FORCE_X0): the class to feed back instead of the argmax
   int sampler;
   ddp_step st;
   int rows;

@@ -1573,6 +1573,10 @@ __global__ void __launch_bounds__(256) k_seg_update(SegUpdateArgs a) {
   // the LUT in range - the NaN then propagates through the update arithmetic instead of faulting (the tail kernel does the same)
   if (bi >= K) bi = 0;
   if (a.x0_idx && lane == 0) a.x0_idx[m] = (unsigned char)bi;
+  if (a.x0_force) {               // teacher forcing (DDP_FLAG_FORCE_X0): the caller's class goes into the update, not the argmax
+    bi = a.x0_force[m];
+    if (bi >= K) bi = 0;
+  }
   if (a.prob && a.prob_mode) {
     float* pr = a.prob + size_t(m) * a.ldl;
     if (a.prob_mode == 3) {

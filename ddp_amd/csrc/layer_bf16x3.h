@@ -90,6 +90,7 @@ struct LayerArgs {
   float* prob;                   // (M, ldl) accumulated softmax / last-step scores
   unsigned short* mask_sb;       // SB noisy map m_t (256 ch): read, replaced by m_{t_next}
   unsigned char* x0_idx;         // optional (DDP_FLAG_RECORD_X0): the step's argmax class per token
+  const unsigned char* x0_force; // FORCE instantiations (DDP_FLAG_FORCE_X0): the class fed back INSTEAD of the argmax
   int num_classes, ldl, prob_mode;   // prob_mode: 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = scores
   float alpha, sigma, alpha_next, sigma_next;
   // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
@@ -348,7 +349,7 @@ __device__ __forceinline__ void st_stream(float* p, const f32x4& v) {
   else *reinterpret_cast<f32x4*>(p) = v;
 }
 
-template <int TAG, int MODE = 0, int NCH = 0, bool NT = false>
+template <int TAG, int MODE = 0, int NCH = 0, bool NT = false, bool FORCE = false>
 __global__ void __launch_bounds__(LYR_THREADS, 1)
 k_layer(LayerArgs la) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -886,6 +887,12 @@ k_layer(LayerArgs la) {
       // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
       if (!valid || bi >= K) bi = 0;
       if (la.x0_idx && valid && h == 0) la.x0_idx[m] = (unsigned char)bi;
+      if constexpr (FORCE) {      // teacher forcing: a test instrument in its own instantiations, the product's tails do not have it
+        if (valid) {
+          bi = la.x0_force[m];
+          if (bi >= K) bi = 0;
+        }
+      }
       // Every global load of the epilogue is issued in a batch ahead of its consumers.  The straightforward loops (load 5,
       // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
       // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores

@@ -45,6 +45,8 @@ class DDP(nn.Module, _SamplerMixin):
         super().__init__()
         if not ddim:
             raise NotImplementedError('the reference references ddpm_step but never defines it (depther/ddp.py:244)')
+        if learned_sinusoidal_dim != 16:
+            raise ValueError('libddp_mi355x is built for learned_sinusoidal_dim=16')
         self.backbone = build_backbone(backbone) if backbone is not None else None
         self.neck = _build_neck(neck)
         if isinstance(decode_head, dict) and decode_head.get('type') == 'DeformableHeadWithTime':

@@ -110,7 +110,7 @@ class DDPEngine:
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
                  weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False,
-                 gather_guess_zero=False):
+                 gather_guess_zero=False, force_x0=False):
         self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -150,6 +150,10 @@ class DDPEngine:
         cfg.flags = (0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE)
         if record_x0:
             cfg.flags |= _lib.FLAG_RECORD_X0
+        if force_x0:               # test instrument (seg): teacher forcing, see set_x0_decisions()
+            if task != 'seg':
+                raise ValueError('force_x0 is a segmentation test instrument')
+            cfg.flags |= _lib.FLAG_FORCE_X0
         if gather_guess_zero:      # diagnostic: forces the LDS gather's refill branch (identical results)
             cfg.flags |= _lib.FLAG_GATHER_GUESS_ZERO
         self.fused_layer = bool(fused_layer)
@@ -210,6 +214,7 @@ class DDPEngine:
                 _lib.check(self.lib.ddp_prepare_geometry(C.byref(n), ws.data_ptr(), self._stream()), self.lib)
         self.cfg, self.workspace = n, ws
         self.geometry_changes += 1
+        self._x0_set = False       # force_x0: the decisions buffer belongs to the geometry region
         return self
 
     def out_shape(self):
@@ -236,6 +241,8 @@ class DDPEngine:
             assert step_noise is not None and step_noise.is_contiguous() and step_noise.numel() == c.timesteps * noise.numel()
         if not self._prepared:
             self.prepare()
+        if (c.flags & _lib.FLAG_FORCE_X0) and not getattr(self, '_x0_set', False):
+            raise _lib.DdpError('force_x0 engine: call set_x0_decisions() before sample()')
         if out is None:
             out = torch.empty(self.out_shape(), dtype=torch.float32, device=self.device)
         if x.device != self.device or noise.device != self.device or out.device != self.device:
@@ -270,14 +277,30 @@ class DDPEngine:
             self.sample(sx, sn, ssn, out=out)
         return SampleGraph(self, g, sx, sn, ssn, out)
 
-    def x0_trace(self):
-        """(K, B*r, h, w) uint8: the x0 class every step of the LAST sample() call fed back (needs record_x0=True)."""
+    def _x0_view(self, which):
         c = self.cfg
         p = C.c_void_p()
         _lib.check(self.lib.ddp_x0_trace(C.byref(c), self.workspace.data_ptr(), C.byref(p)), self.lib)
-        off = p.value - self.workspace.data_ptr()
         n = c.timesteps * c.batch * c.randsteps * c.head_h * c.head_w
-        return self.workspace.view(torch.uint8)[off:off + n].view(c.timesteps, c.batch * c.randsteps, c.head_h, c.head_w).clone()
+        off = p.value - self.workspace.data_ptr() + which * n
+        return self.workspace.view(torch.uint8)[off:off + n].view(c.timesteps, c.batch * c.randsteps, c.head_h, c.head_w)
+
+    def x0_trace(self):
+        """(K, B*r, h, w) uint8: the argmax class every step of the LAST sample() call found (needs record_x0=True or
+        force_x0=True; record_x0: that is also what the step fed back, force_x0: the step fed back set_x0_decisions()'s)."""
+        return self._x0_view(1 if self.cfg.flags & _lib.FLAG_FORCE_X0 else 0).clone()
+
+    def set_x0_decisions(self, decisions):
+        """force_x0=True (test instrument, DDP_FLAG_FORCE_X0): the classes (K, B*r, h, w) every step of the following sample()
+        calls feeds back instead of its own argmax - e.g. the decisions a reference run recorded (tests/golden/full_*.npz)."""
+        if not self.cfg.flags & _lib.FLAG_FORCE_X0:
+            raise _lib.DdpError('set_x0_decisions needs an engine built with force_x0=True')
+        v = self._x0_view(0)
+        d = decisions.to(device=self.device, dtype=torch.uint8).reshape(v.shape)
+        if int(d.max()) >= self.cfg.num_classes:
+            raise ValueError('decision outside [0, num_classes)')
+        v.copy_(d)
+        self._x0_set = True
 
     def head_forward(self, feat, temb):
         """DeformableHeadWithTime.forward on (R,256,h,w) + (1|R,1024) time embedding."""
@@ -306,10 +329,20 @@ class SampleGraph:
         self.engine, self.graph = engine, graph
         self.x, self.noise, self.step_noise, self.out = x, noise, step_noise, out
         self.geometry = engine.geometry()
+        # the graph has the workspace's ADDRESS baked into every launch: keep that allocation alive for as long as the graph
+        # exists (a replay can then never touch freed memory) and refuse to replay once the engine has moved to another one
+        self.workspace = engine.workspace
+        self.workspace_ptr = engine.workspace.data_ptr()
 
     def replay(self, x=None, noise=None, step_noise=None):
-        if self.engine.geometry() != self.geometry:
-            raise _lib.DdpError(f'graph captured for geometry {self.geometry}, engine is now at {self.engine.geometry()}')
+        eng = self.engine
+        if eng.geometry() != self.geometry:
+            raise _lib.DdpError(f'graph captured for geometry {self.geometry}, engine is now at {eng.geometry()}')
+        if eng.workspace.data_ptr() != self.workspace_ptr:
+            raise _lib.DdpError('stale graph: the engine\'s workspace was reallocated after the capture (set_geometry grew it); '
+                                'capture again')
+        if not eng._prepared:      # head_forward() rewrote the FiLM slot of step 0: restore the constants (same addresses)
+            eng.prepare()
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if noise is not None:

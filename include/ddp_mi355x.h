@@ -64,9 +64,15 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
  * the unfused kernels covered).  UNFUSED_LAYER implies the unfused step head and seg tail as well.
  * GATHER_GUESS_ZERO: the LDS-staged gather starts every window from a zero guess of the head's mean sampling offset instead
  * of the mean of its offset biases, which forces its "actual mean is far from the guess: refill" branch (identical results:
- * the window origin only decides which taps are served from LDS). */
+ * the window origin only decides which taps are served from LDS).
+ * FORCE_X0 (seg, test instrument): teacher forcing.  Every step feeds back the class the CALLER supplies (ddp_x0_trace's
+ * buffer, filled before ddp_sample) instead of its own argmax (ddp.py:235); scores, softmax accumulation, update and
+ * everything else are unchanged, and the step's OWN argmax is still recorded next to the supplied one.  With the
+ * decisions of a reference run supplied, the loop has no discontinuity left and the outputs must agree with that run to
+ * rounding (tests/test_fullsize_reference.py).  Separate kernel instantiations: the product's tails are not touched. */
 enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8,
-       DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */ };
+       DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */,
+       DDP_FLAG_FORCE_X0 = 32 };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -167,7 +173,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
  * the workspace - the x0 class (argmax of the step's scores, ddp.py:235) every step fed back.  The loop's only
  * discontinuity is this discrete choice; with it recorded, parity splits into "same decisions -> outputs agree to
  * rounding" and "decisions differ only where the reference's own top-2 gap is at rounding level"
- * (tests/test_full_size_parity.py). */
+ * (tests/test_full_size_parity.py).
+ * With DDP_FLAG_FORCE_X0 the buffer is (2, K, B*r*h*w): [0] = the decisions to feed back, written by the caller BEFORE
+ * ddp_sample (values < num_classes); [1] = the argmax the engine itself found at every step under that forcing. */
 int ddp_x0_trace(const ddp_cfg* cfg, void* d_workspace, const unsigned char** d_idx);
 
 /* ---- finer-grained entry points (unit tests, and the decode_head plugin surface) ------------- */

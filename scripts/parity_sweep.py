@@ -26,12 +26,17 @@ CONFIGS = {   # name: (B, h, w, K, classes, layers, accumulation, oracle variant
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
+    ap.add_argument('--config', choices=sorted(CONFIGS) + ['c3_trained'], default='c2')
     ap.add_argument('--images', default='', help='comma-separated image indices (default: all of the batch)')
     ap.add_argument('--weights-seed', type=int, default=None)
     ap.add_argument('--inputs-seed', type=int, default=None)
     ap.add_argument('--variants', default='', help="reference-vs-reference variants, e.g. 'taps' or 'taps,fp64' (default: the config's)")
     args = ap.parse_args()
+    if args.config == 'c3_trained':     # the trained-like weight profile at the Cityscapes map size against fp64 (until round 4 part of
+        torch.set_num_threads(T._usable_cores())      # the suite as test_c3_size_trained_like_weights: ~3 CPU-minutes of oracle)
+        T.c3_size_trained_like_weights(torch.device('cuda:0'))
+        print('c3_trained: assertions hold')
+        return
     B, h, w, K, ncls, L, acc, variants, wseed, iseed = CONFIGS[args.config]
     wseed = wseed if args.weights_seed is None else args.weights_seed
     iseed = iseed if args.inputs_seed is None else args.inputs_seed

@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 from ddp_amd.utils import synthetic  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from golden_util import class_projection_weights  # noqa: E402
 
 SEG_CASES = [
     # ADE-like: 150 classes, accumulation (configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py:13-15)
@@ -51,6 +53,12 @@ SEG_CASES = [
     # ancestral sampler (segmentors/ddp.py:248-290)
     dict(name='seg_ddpm', h=10, w=14, num_classes=19, timesteps=4, randsteps=1, bit_scale=0.01,
          accumulation=True, noise_schedule='cosine', diffusion='ddpm', seed=5, trace=False),
+    # time_difference != 1 (segmentors/ddp.py:204-213: t_next = max(1 - (step + 1 + td) / K, sample_range[0])): 0 = the plain
+    # DDIM grid, 2 = the last two steps both jump to t = 0
+    dict(name='seg_td0', h=9, w=14, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=6, trace=False, time_difference=0),
+    dict(name='seg_td2', h=8, w=11, num_classes=150, timesteps=4, randsteps=2, bit_scale=0.01,
+         accumulation=False, noise_schedule='cosine', diffusion='ddim', seed=7, trace=False, time_difference=2),
 ]
 
 DEPTH_CASES = [
@@ -58,6 +66,8 @@ DEPTH_CASES = [
          min_depth=1e-3, max_depth=80.0),
     dict(name='depth_k20', h=8, w=12, timesteps=20, randsteps=1, bit_scale=0.1, seed=11,
          min_depth=1e-3, max_depth=80.0),
+    dict(name='depth_td2', h=7, w=13, timesteps=4, randsteps=1, bit_scale=0.1, seed=12,
+         min_depth=1e-3, max_depth=80.0, time_difference=2),
 ]
 
 BEV_CASES = [
@@ -69,6 +79,14 @@ BEV_CASES = [
     dict(name='bev_camera', h=12, w=20, feat_channels=256, timesteps=2, randsteps=1, bit_scale=0.01,
          num_layers=5, seed=21, input_scope=[[-51.2, 51.2, 8.533333333333333], [-51.2, 51.2, 5.12]],
          output_scope=[[-50, 50, 5.0], [-50, 50, 3.125]]),
+    # the SHIPPED sampler settings (bev/configs/nuscenes/seg/ddp-fusion-bev256d2-lss-scale001-d5-lr5e-5.yaml:5 randsteps: 4;
+    # ddp-camera-bev256d2-lss-scale001-d5-lr5e-5.yaml:6 randsteps: 5) on small maps
+    dict(name='bev_fusion_r4', h=16, w=16, feat_channels=512, timesteps=3, randsteps=4, bit_scale=0.01,
+         num_layers=5, seed=22, input_scope=[[-51.2, 51.2, 6.4], [-51.2, 51.2, 6.4]],
+         output_scope=[[-50, 50, 5.0], [-50, 50, 5.0]]),
+    dict(name='bev_camera_r5', h=14, w=10, feat_channels=256, timesteps=3, randsteps=5, bit_scale=0.01,
+         num_layers=5, seed=23, input_scope=[[-51.2, 51.2, 7.314285714285714], [-51.2, 51.2, 10.24]],
+         output_scope=[[-50, 50, 4.0], [-50, 50, 6.25]]),
 ]
 
 
@@ -148,6 +166,8 @@ def gen_seg():
         m.diffusion = case['diffusion']
         if 'sample_range' in case:
             m.sample_range = tuple(case['sample_range'])
+        if 'time_difference' in case:
+            m.time_difference = case['time_difference']
         m.decode_head.num_classes = case['num_classes']
         m.auxiliary_head.num_classes = case['num_classes']
         model = revert(build_segmentor(m)).eval()
@@ -205,6 +225,8 @@ def gen_depth():
         m.bit_scale = case['bit_scale']
         m.min_depth = case['min_depth']
         m.max_depth = case['max_depth']
+        if 'time_difference' in case:
+            m.time_difference = case['time_difference']
         model = revert_sync_batchnorm(build_depther(m)).eval()
         assert hasattr(model.decode_head.encoder.layers[0], 'time_mlp'), 'time-aware layer not registered'
         sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=case['seed'] + 100)
@@ -393,7 +415,6 @@ def gen_slide():
     slide_inference / DDP.encode_decode; backbone and sampler replaced by seeded low-resolution scores, one per window."""
     import ref_shim
     build_segmentor, Config, revert = ref_shim.import_seg()
-    from ddp_amd.engine import slide_windows
     cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
     for case in SLIDE_CASES:
         cfg = Config.fromfile(cfg_path)
@@ -407,27 +428,39 @@ def gen_slide():
         m.auxiliary_head.num_classes = case['num_classes']
         model = revert(build_segmentor(m)).eval()
         model.align_corners = case['align_corners']
-        ys, xs, (ch, cw) = slide_windows(case['img'], case['crop_size'], case['stride'])
-        n_win = len(ys) * len(xs)
-        scores = [synthetic.make_scores(1, case['num_classes'], case['h'], case['w'], case['seed'] * 100 + i) for i in range(n_win)]
-        calls = []
-        shapes = []
-        model.extract_feat = lambda img, _s=shapes: (_s.append(tuple(img.shape[2:])), [None])[1]
+        # the window grid is RECORDED from the reference (nothing of the product is imported here): the image carries its own
+        # pixel coordinates in channels 0 / 1, so every crop slide_inference hands to encode_decode -> extract_feat tells where
+        # it was cut (y1, x1) and how large it is; window i gets the seeded scores i (one sampler call per window)
+        H, W = case['img']
+        img = torch.zeros((1, 3, H, W))
+        img[0, 0] = torch.arange(H, dtype=torch.float32).view(H, 1)
+        img[0, 1] = torch.arange(W, dtype=torch.float32).view(1, W)
+        windows, calls, state = [], [], dict(n=None)
 
-        def sample(x, img_metas, _calls=calls, _scores=scores):
+        def extract(im, _w=windows):
+            y1, x1 = int(im[0, 0, 0, 0]), int(im[0, 1, 0, 0])
+            _w.append((y1, x1, y1 + im.shape[2], x1 + im.shape[3]))
+            return [None]
+        model.extract_feat = extract
+
+        def sample(x, img_metas, _calls=calls):
+            i = len(_calls) if state['n'] is None else len(_calls) % state['n']
             _calls.append(1)
-            return _scores[(len(_calls) - 1) % len(_scores)].clone()
+            return synthetic.make_scores(1, case['num_classes'], case['h'], case['w'], case['seed'] * 100 + i)
         model.ddim_sample = sample
-        img = torch.zeros((1, 3) + tuple(case['img']))
         meta = [dict(img_shape=tuple(case['img_shape']) + (3,), ori_shape=tuple(case['ori_shape']) + (3,),
                      pad_shape=tuple(case['img']) + (3,), flip=case['flip'] is not None, flip_direction=case['flip'] or 'horizontal')]
         seg = model.simple_test(img, meta, rescale=True)[0]
-        assert len(calls) == n_win and all(s == (ch, cw) for s in shapes), (len(calls), n_win, shapes[:3], (ch, cw))
+        n_win = state['n'] = len(calls)
+        win = list(windows)
+        assert len(win) == n_win
         prob = model.inference(img, meta, True)
-        assert (prob.argmax(1)[0].numpy() == seg).all()
+        assert windows[n_win:] == win and (prob.argmax(1)[0].numpy() == seg).all()
+        scores = [synthetic.make_scores(1, case['num_classes'], case['h'], case['w'], case['seed'] * 100 + i) for i in range(n_win)]
         top2 = prob.topk(2, dim=1).values
         save(case['name'], dict(task='slide', n_windows=n_win, **case),
-             dict(seg=seg.astype('uint8'), prob=prob[0], margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=np.stack([fingerprint(t) for t in scores])))
+             dict(seg=seg.astype('uint8'), prob=prob[0], margin=(top2[:, 0] - top2[:, 1])[0], scores_fp=np.stack([fingerprint(t) for t in scores]),
+                  windows=np.asarray(win, dtype=np.int32)))
 
 
 DPOST_CASES = [
@@ -673,18 +706,159 @@ def gen_loopfcn():
                   weights_fp=synthetic.checksum(sd)))
 
 
+# ---- full-size fixtures (VERDICT r04 "next" #1): the REFERENCE itself at the sizes of BASELINE.json's configurations, one image each.
+# Inputs / weights = the seeds tests/test_full_size_parity.py uses for the batch of that configuration (image ``b`` of a
+# ``B``-image draw), so the GPU test runs the engine once on the whole batch and compares image b.  Stored compactly:
+#   seg  : per-step argmax decisions (uint8), per-step top-2 gap (fp16, clipped at 1e-2 of the score scale - only small gaps
+#          matter), per-step score scale, the final class map, the final scores on every ``stride``-th pixel (all classes,
+#          fp32) and a seeded class-weighted projection of the final scores at EVERY pixel (one fp32 per pixel);
+#   depth: the final map and the per-step predictions on every 16th pixel;   bev: the final map (r = 4: every 2nd pixel).
+FULLSIZE_SEG = [
+    dict(name='full_c1', B=1, b=0, h=128, w=128, num_classes=150, timesteps=1, accumulation=True, sd_seed=2, in_seed=10, stride=11),
+    dict(name='full_c2', B=8, b=0, h=128, w=256, num_classes=150, timesteps=3, accumulation=True, sd_seed=2, in_seed=0, stride=11),
+    dict(name='full_c3', B=4, b=2, h=256, w=512, num_classes=19, timesteps=10, accumulation=False, sd_seed=3, in_seed=30, stride=7),
+]
+FULLSIZE_DEPTH = [
+    dict(name='full_c4', B=16, b=0, h=88, w=304, timesteps=20, sd_seed=4, in_seed=40, bit_scale=0.1, min_depth=1e-3, max_depth=80.0),
+]
+_BEV_SCOPES = dict(input_scope=[[-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8]], output_scope=[[-50, 50, 0.5], [-50, 50, 0.5]])
+FULLSIZE_BEV = [
+    # the shape of BASELINE.json configs[4] (fusion features 512 ch at 128^2 -> 200^2 decoder grid, 5 layers, 6 classes, K = 3)
+    dict(name='full_c5_r1', B=8, b=0, h=128, w=128, feat_channels=512, timesteps=3, randsteps=1, bit_scale=0.01, num_layers=5,
+         sd_seed=5, in_seed=50, stride=1, **_BEV_SCOPES),
+    # the SHIPPED sampler setting: bev/configs/nuscenes/seg/ddp-fusion-bev256d2-lss-scale001-d5-lr5e-5.yaml:5  randsteps: 4
+    dict(name='full_c5_r4', B=2, b=1, h=128, w=128, feat_channels=512, timesteps=3, randsteps=4, bit_scale=0.01, num_layers=5,
+         sd_seed=5, in_seed=52, stride=2, **_BEV_SCOPES),
+]
+
+
+def gen_fullsize_seg():
+    import ref_shim
+    build_segmentor, Config, revert = ref_shim.import_seg()
+    cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+    for case in FULLSIZE_SEG:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.timesteps, m.randsteps, m.bit_scale, m.accumulation = case['timesteps'], 1, 0.01, case['accumulation']
+        m.decode_head.num_classes = case['num_classes']
+        m.auxiliary_head.num_classes = case['num_classes']
+        model = revert(build_segmentor(m)).eval()
+        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['sd_seed'])
+        load_hot_path(model, sd)
+        xb, nb = synthetic.make_inputs(case['B'], case['h'], case['w'], 1, 256, 256, seed=case['in_seed'])
+        b = case['b']
+        x, noise = xb[b:b + 1].clone(), nb[b].clone()
+        del xb, nb
+        logits = []
+        wrap_forward(model.decode_head, logits)
+        with RandnPatch(noise):
+            out = model.ddim_sample(x, None)
+        K = case['timesteps']
+        assert len(logits) == K
+        dec = torch.stack([lg.argmax(1)[0] for lg in logits]).to(torch.uint8)                       # (K,h,w)
+        scale = torch.tensor([float(lg.abs().max()) for lg in logits])
+        gaps = []
+        for s, lg in enumerate(logits):
+            t2 = lg.topk(2, dim=1).values
+            gaps.append((t2[:, 0] - t2[:, 1])[0].clamp(max=1e-2 * float(scale[s])))
+        gap = torch.stack(gaps).to(torch.float16)
+        flat = out[0].reshape(case['num_classes'], -1)
+        idx = torch.arange(0, flat.shape[1], case['stride'])
+        proj = (out[0] * class_projection_weights(case['num_classes']).view(-1, 1, 1)).sum(0)
+        save(case['name'], dict(task='fullsize_seg', **case),
+             dict(decisions=dec, gap=gap, score_scale=scale, final_cls=out[0].argmax(0).to(torch.uint8),
+                  out_sub=flat[:, idx].contiguous(), out_absmax=float(out.abs().max()), out_proj=proj,
+                  x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
+
+
+def gen_fullsize_depth():
+    import ref_shim
+    build_depther, Config = ref_shim.import_depth()
+    from mmcv.cnn.utils import revert_sync_batchnorm
+    cfg_path = os.path.join(ref_shim.REF, 'depth/configs/ddp_kitti/ddp_swint_1k_w7_kitti_bs2x8_scale01.py')
+    for case in FULLSIZE_DEPTH:
+        cfg = Config.fromfile(cfg_path)
+        m = cfg.model
+        m.backbone.init_cfg = None
+        m.train_cfg = None
+        m.timesteps, m.randsteps, m.bit_scale = case['timesteps'], 1, case['bit_scale']
+        m.min_depth, m.max_depth = case['min_depth'], case['max_depth']
+        model = revert_sync_batchnorm(build_depther(m)).eval()
+        assert hasattr(model.decode_head.encoder.layers[0], 'time_mlp'), 'time-aware layer not registered'
+        sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=case['sd_seed'])
+        load_hot_path(model, sd)
+        xb, nb = synthetic.make_inputs(case['B'], case['h'], case['w'], 1, 256, 1, seed=case['in_seed'])
+        x, noise = xb[case['b']:case['b'] + 1].clone(), nb[case['b']].clone()
+        preds = []
+        wrap_forward(model.decode_head, preds)
+        with RandnPatch(noise):
+            out = model.sample(x, None)
+        ps = torch.stack([p.reshape(-1)[::16] for p in preds])
+        save(case['name'], dict(task='fullsize_depth', **case),
+             dict(out=out, pred_steps_sub=ps, x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
+
+
+def gen_fullsize_bev():
+    import ref_shim
+    ddp_mod, head_mod = ref_shim.import_bev()
+    from mmcv.utils import ConfigDict
+    for case in FULLSIZE_BEV:
+        nl = case['num_layers']
+        encoder = dict(
+            type='DetrTransformerEncoder', num_layers=nl,
+            transformerlayers=dict(
+                type='BaseTransformerLayer', use_time_mlp=True,
+                attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256, num_levels=1, num_heads=8, dropout=0.0),
+                ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, ffn_drop=0., act_cfg=dict(type='GELU')),
+                operation_order=('self_attn', 'norm', 'ffn', 'norm')))
+        head = head_mod.DeformableHeadWithTime(
+            num_feature_levels=1, encoder=ConfigDict(encoder),
+            positional_encoding=ConfigDict(dict(type='SinePositionalEncoding', num_feats=128, normalize=True, offset=-0.5)),
+            classes=['a', 'b', 'c', 'd', 'e', 'f'], loss='focal',
+            grid_transform=dict(input_scope=case['input_scope'], output_scope=case['output_scope']), in_channels=256).eval()
+        model = ddp_mod.DDP(bit_scale=case['bit_scale'], timesteps=case['timesteps'], randsteps=case['randsteps'],
+                            feat_channels=case['feat_channels']).eval()
+        sd = synthetic.make_state_dict('bev', 6, nl, case['feat_channels'], seed=case['sd_seed'])
+        res = model.load_state_dict({k: v for k, v in sd.items() if not k.startswith('decode_head.')}, strict=False)
+        assert not res.unexpected_keys and not res.missing_keys, res
+        res = head.load_state_dict({k[len('decode_head.'):]: v for k, v in sd.items() if k.startswith('decode_head.')}, strict=False)
+        assert not res.unexpected_keys and not res.missing_keys, res
+        xb, nb = synthetic.make_inputs(case['B'], case['h'], case['w'], case['randsteps'], case['feat_channels'], 256, seed=case['in_seed'])
+        x, noise = xb[case['b']:case['b'] + 1].clone(), nb[case['b']].clone()
+        del xb, nb
+        probs = []
+        hk = head.register_forward_hook(lambda mod, i, o: probs.append(o.clone()))
+        with RandnPatch(noise):
+            out = model.ddim_sample([x], head)
+        hk.remove()
+        # how close the fed-back thresholded maps come to a tie: smallest |prob - 0.5| per step
+        margin = torch.tensor([float((p - 0.5).abs().min()) for p in probs])
+        st = case['stride']
+        save(case['name'], dict(task='fullsize_bev', **case),
+             dict(out_sub=out[:, :, ::st, ::st].contiguous(), out_absmax=float(out.abs().max()), out_mean=out.mean(1)[0],
+                  thr_margin=margin, x_fp=fingerprint(x), noise_fp=fingerprint(noise), weights_fp=synthetic.checksum(sd)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide', 'all'], default='all')
+    ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide', 'fullsize',
+                                      'fullsize_seg', 'fullsize_depth', 'fullsize_bev', 'all'], default='all')
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.task == 'all':
         for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide'):       # separate processes: the trees' registries collide
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
         return
+    if args.task == 'fullsize':       # not part of 'all': ~6 CPU-minutes, the reference at BASELINE.json's sizes
+        for t in ('fullsize_seg', 'fullsize_depth', 'fullsize_bev'):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--task', t])
+        return
     with torch.no_grad():
         {'seg': gen_seg, 'depth': gen_depth, 'bev': gen_bev, 'post': gen_post, 'neck': gen_neck, 'fcn': gen_fcn, 'fpn': gen_fpn,
-         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug, 'dpost': gen_dpost, 'slide': gen_slide}[args.task]()
+         'aligned': gen_aligned, 'loopfcn': gen_loopfcn, 'aug': gen_aug, 'dpost': gen_dpost, 'slide': gen_slide,
+         'fullsize_seg': gen_fullsize_seg, 'fullsize_depth': gen_fullsize_depth, 'fullsize_bev': gen_fullsize_bev}[args.task]()
 
 
 if __name__ == '__main__':

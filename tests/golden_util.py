@@ -17,7 +17,7 @@ def case_names(task=None):
     if task is not None:
         names = [n for n in names if n.startswith(task)]
     else:
-        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide'))]   # other rows: load_post_case / ...
+        names = [n for n in names if not n.startswith(('post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide', 'full'))]   # other rows: load_post_case / ...
     return names
 
 
@@ -48,6 +48,33 @@ def load_case(name):
     return cfg, sd, x, noise[0], step_noise, arrays
 
 
+def class_projection_weights(num_classes, seed=1234):
+    """seeded positive per-class weights of the every-pixel projection stored in the full-size seg fixtures (``out_proj``)"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand((num_classes,), generator=g, dtype=torch.float32) + 0.5
+
+
+FULLSIZE_TASKS = {'fullsize_seg': 'seg', 'fullsize_depth': 'depth', 'fullsize_bev': 'bev'}
+
+
+def load_fullsize_case(name):
+    """Full-size fixture made by the REFERENCE at a BASELINE.json configuration (tests/golden/gen_golden.py --task fullsize):
+    -> (cfg, sd, x (B,Cx,h,w), noise (B,r,Cm,h,w), arrays).  The reference ran image ``cfg['b']`` of this seeded batch; the
+    stored fingerprints are of that image."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    cfg = json.loads(str(z['config']))
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if k != 'config'}
+    task = FULLSIZE_TASKS[cfg['task']]
+    cx = cfg.get('feat_channels', 256)
+    sd = synthetic.make_state_dict(task, cfg.get('num_classes', 6 if task == 'bev' else 1), cfg.get('num_layers', 6), cx, seed=cfg['sd_seed'])
+    x, noise = synthetic.make_inputs(cfg['B'], cfg['h'], cfg['w'], cfg.get('randsteps', 1), cx, 1 if task == 'depth' else 256, seed=cfg['in_seed'])
+    b = cfg['b']
+    assert abs(synthetic.checksum(sd) - float(arrays['weights_fp'])) <= 1e-9 * abs(float(arrays['weights_fp']))
+    assert np.allclose(fingerprint(x[b:b + 1]), arrays['x_fp'].numpy(), rtol=1e-12)
+    assert np.allclose(fingerprint(noise[b]), arrays['noise_fp'].numpy(), rtol=1e-12)
+    return cfg, sd, x, noise, arrays
+
+
 def max_rel(a, b):
     """max |a-b| / max |b|  (the parity metric of SURVEY.md §8d)."""
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
@@ -74,12 +101,24 @@ def load_aug_case(name):
 
 def load_slide_case(name):
     """Sliding-window fixture (reference ``simple_test`` / ``inference`` with test_cfg.mode='slide'): -> (cfg, [window scores
-    (1,K,h,w)] row-major over the grid, seg uint8 (oh,ow), prob (K,oh,ow), margin (oh,ow))."""
+    (1,K,h,w)] row-major over the grid, seg uint8 (oh,ow), prob (K,oh,ow), margin (oh,ow)).  cfg['windows'] = the (y1,x1,y2,x2)
+    list the REFERENCE's slide_inference cut (recorded by the generator from the crops it handed to extract_feat), call order."""
     z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
     cfg = json.loads(str(z['config']))
+    cfg['windows'] = [tuple(int(v) for v in r) for r in z['windows']]
     scores = [synthetic.make_scores(1, cfg['num_classes'], cfg['h'], cfg['w'], cfg['seed'] * 100 + i) for i in range(cfg['n_windows'])]
     assert np.allclose(np.array([fingerprint(t) for t in scores]), z['scores_fp'], rtol=1e-12)
     return cfg, scores, torch.from_numpy(z['seg']), torch.from_numpy(z['prob']), torch.from_numpy(z['margin'])
+
+
+def reference_window_grid(cfg):
+    """(ys, xs, crop) of a slide fixture from the window list the REFERENCE cut (row-major: all columns of a row first)."""
+    win = cfg['windows']
+    ys = sorted({w[0] for w in win}, key=[w[0] for w in win].index)
+    xs = sorted({w[1] for w in win}, key=[w[1] for w in win].index)
+    crop = (win[0][2] - win[0][0], win[0][3] - win[0][1])
+    assert win == [(y, x, y + crop[0], x + crop[1]) for y in ys for x in xs], 'reference windows are not a row-major grid'
+    return ys, xs, crop
 
 
 def load_dpost_case(name):

@@ -28,7 +28,7 @@ def _engine(cfg, sd, dev, batch=1, **over):
     from ddp_amd.engine import DDPEngine
     task = cfg['task']
     kw = dict(h=cfg['h'], w=cfg['w'], batch=batch, randsteps=cfg['randsteps'], timesteps=cfg['timesteps'],
-              bit_scale=cfg['bit_scale'], device=dev)
+              bit_scale=cfg['bit_scale'], time_difference=cfg.get('time_difference', 1), device=dev)
     if task == 'seg':
         kw.update(num_classes=cfg['num_classes'], accumulation=cfg['accumulation'],
                   noise_schedule=cfg['noise_schedule'], sampler=cfg['diffusion'],
@@ -363,10 +363,11 @@ def test_slide_epilogue_golden(name):
     """fused sliding-window epilogue (ddp_seg_slide_postprocess) vs the reference's own slide_inference / inference / simple_test:
     probabilities to rounding, class map identical wherever the reference's top-2 margin is above interpolation / exp noise;
     the three outputs (class map, probabilities, averaged scores) are consistent with each other."""
-    from golden_util import load_slide_case
+    from golden_util import load_slide_case, reference_window_grid
     from ddp_amd.engine import seg_slide_postprocess, slide_windows
     cfg, scores, seg, prob, margin = load_slide_case(name)
-    ys, xs, crop = slide_windows(cfg['img'], cfg['crop_size'], cfg['stride'])
+    ys, xs, crop = reference_window_grid(cfg)                           # the grid the REFERENCE cut, recorded in the fixture
+    assert slide_windows(cfg['img'], cfg['crop_size'], cfg['stride']) == (ys, xs, crop)      # ... and the product's is the same
     sc = torch.stack(scores).cuda()                                     # (windows, 1, K, h, w)
     args = (sc, ys, xs, crop, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'])
     got = seg_slide_postprocess(*args, flip=cfg['flip'], want='seg')[0].cpu()

@@ -585,3 +585,26 @@ def test_new_entry_points_validate_on_the_host():
     fpn_bytes = n.value
     assert lib.ddp_neck_fpn_msm_workspace(lv, 1, ctypes.byref(n)) == 0 and n.value > fpn_bytes
     assert lib.ddp_profile_read(99, None, None) == -1 and lib.ddp_profile_read(7, None, None) == -1        # unknown tag / no session
+
+
+def test_learned_sinusoidal_dim_guard():
+    """The library's time-embedding kernel is built for the reference default ``learned_sinusoidal_dim=16`` (every shipped config;
+    segmentors/ddp.py:62, depther/ddp.py:48, fusion_models/ddp.py:73): any other value is refused at construction by all three
+    drop-in classes instead of producing a state_dict the kernels would misread."""
+    from ddp_amd.bev.ddp import DDP as BevDDP
+    from ddp_amd.depther.ddp import DDP as DepthDDP
+    from ddp_amd.segmentors.ddp import DDP as SegDDP
+    head = dict(type='DeformableHeadWithTime', in_channels=[256], in_index=[0], channels=256, num_classes=19, dropout_ratio=0.0,
+                num_feature_levels=1, align_corners=False,
+                encoder=dict(type='DetrTransformerEncoder', num_layers=1, transformerlayers=dict(
+                    type='BaseTransformerLayer', use_time_mlp=True,
+                    attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256, num_levels=1, num_heads=8, dropout=0.0),
+                    ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, ffn_drop=0., act_cfg=dict(type='GELU')),
+                    operation_order=('self_attn', 'norm', 'ffn', 'norm'))),
+                positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True, offset=-0.5))
+    for make in (lambda d: SegDDP(decode_head=dict(head), learned_sinusoidal_dim=d),
+                 lambda d: DepthDDP(decode_head=dict(head), learned_sinusoidal_dim=d),
+                 lambda d: BevDDP(learned_sinusoidal_dim=d)):
+        with pytest.raises(ValueError, match='learned_sinusoidal_dim'):
+            make(8)
+    BevDDP(learned_sinusoidal_dim=16)

