@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libddp_mi355x.so')
-SOURCES = ['ddp_api.hip', 'ddp_gemm.hip', 'ddp_gemm_bf16.hip', 'ddp_kernels.hip']
+SOURCES = ['ddp_api.hip', 'ddp_gemm.hip', 'ddp_gemm_bf16.hip', 'ddp_kernels.hip', 'ddp_layer_tail.hip']
 HEADERS = ['exports.map', 'ddp_internal.h', 'gemm_f32.h', 'gemm_bf16x3.h', 'layer_bf16x3.h', os.path.join('..', '..', 'include', 'ddp_mi355x.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 

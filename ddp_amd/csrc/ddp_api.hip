@@ -102,6 +102,8 @@ struct Layout {
   float* ubuf;                                          // u = W_m . m_t, fp32 fragment-major (fused seg tails)
   float* tlut;                                          // (Kc + 1, 256) = W_m . LUT^T
   unsigned char* tail4_stream;                          // fused tail: conv_seg images + layer 0's 11 projection images
+  unsigned char* lt_stream;                             // last layer + tail (k_layer MODE 6): 72 stages of layer L-1 + tail4_stream
+  float* lt_bias;                                       //   fc1 bias of layer L-1 | layer 0's value_proj bias at [1024, 1280)
   float* tail4_bias;                                    //             conv_seg bias | layer 0's value_proj bias at [1024, 1280)
   unsigned char* tail_stream;                           // seg tail: conv_seg stage images (2 per 64 classes)
   float* tail_bias;                                     //           conv_seg bias, zero padded
@@ -151,7 +153,7 @@ int validate(const ddp_cfg* c) {
     return DDP_E_BADCFG;
   }
   if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO |
-                   DDP_FLAG_FORCE_X0)) {
+                   DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -241,6 +243,9 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
     o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
     o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
+    const bool lt = segp && o->L >= 1 && b3_layer_tail_supported(o->Kc);
+    o->lt_stream = lt ? reinterpret_cast<unsigned char*>(cv.take(size_t(72 + 8 + 11) * 48 * 1024 / sizeof(float))) : nullptr;
+    o->lt_bias = lt ? cv.take(size_t(b3_layer_bias_floats())) : nullptr;
     o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : 0);
   } else {
     o->tail_stream = nullptr;
@@ -249,6 +254,8 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->pro_bias = nullptr;
     o->tail4_stream = nullptr;
     o->tail4_bias = nullptr;
+    o->lt_stream = nullptr;
+    o->lt_bias = nullptr;
     o->tlut = nullptr;
   }
   o->const_bytes = cv.off * sizeof(float);
@@ -491,6 +498,21 @@ int prepare_model(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipSt
         }
       }
     }
+    if (o.lt_stream) {
+      // last layer + tail (k_layer MODE 6): the images do not depend on the step, so ONE concatenated stream serves every step -
+      // [layer L-1: Wo 8 wide, 16 x (fc1 2 tall, fc2 2 wide)][conv_seg 2 tall per 64 classes][layer 0's Wv 8 tall][Wcat 2 tall +
+      // 1 split-K]; after the last step the kernel wraps behind conv_seg.  Bias table: fc1's | layer 0's value_proj bias.
+      const int nch = (o.Kc + 63) / 64;
+      const size_t sb = size_t(48) * 1024;
+      if (hipMemcpyAsync(o.lt_stream, o.wstream[o.L - 1], 72 * sb, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(o.lt_stream + 72 * sb, o.tail4_stream, size_t(2 * nch + 11) * sb, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemsetAsync(o.lt_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          hipMemcpyAsync(o.lt_bias, w->layers[o.L - 1].ffn0_b, DDP_FFN * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(o.lt_bias + DDP_FFN, w->layers[0].value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("layer + tail stream copy failed");
+        return DDP_E_LAUNCH;
+      }
+    }
   }
   return DDP_OK;
 }
@@ -502,8 +524,9 @@ int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
 }
 
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
+// `tail` (seg, u chain): the step's tail is fused into the LAST layer's kernel (k_layer MODE 6) - the caller launches no tail
 int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st, bool l0_projected = false,
-                    bool sb_out = true) {
+                    bool sb_out = true, const TailLaunch* tail = nullptr) {
   const int M = int(o.M);
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
@@ -567,7 +590,8 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         ll.px = ll.has_next ? o.px[l + 1] : nullptr;
         ll.n_tok = o.Nh;
         ll.w = o.wh;
-        DDP_TRY(launch_b3_layer(ll, st));
+        if (tail && l + 1 == o.L) DDP_TRY(launch_b3_layer_tail(ll, *tail, o.lt_stream, o.lt_bias, o.tail_bias, st));
+        else DDP_TRY(launch_b3_layer(ll, st));
       } else {
         DDP_TRY(launch_b3_linear_res_ln(o.s_sb, o.wp_o[l], lw.output_proj_b, nullptr, o.q_sb, lw.norm0_w, lw.norm0_b, nullptr,
                                         o.q1_sb, M, 256, st, TAG_OUTPROJ_LN));
@@ -845,9 +869,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
                                   st));
       }
     }
-    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !seg_tail));
+    TailLaunch tl;
+    memset(&tl, 0, sizeof(tl));
     if (seg_tail) {
-      TailLaunch tl;
       tl.Q = o.q;
       tl.stream = o.tail_stream;
       tl.bias_ext = o.tail_bias;
@@ -883,7 +907,12 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       tl.sigma = sp.sigma;
       tl.alpha_next = sp.alpha_next;
       tl.sigma_next = sp.sigma_next;
-      DDP_TRY(launch_b3_tail(tl, st));
+    }
+    // u chain: the step's tail runs inside the LAST layer's kernel (k_layer MODE 6) - the layer output never leaves the registers
+    const bool lt_fused = seg_tail && u_chain && o.lt_stream && !(cfg->flags & DDP_FLAG_UNFUSED_TAIL);
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !seg_tail, lt_fused ? &tl : nullptr));
+    if (seg_tail) {
+      if (!lt_fused) DDP_TRY(launch_b3_tail(tl, st));
     } else if (cfg->task == DDP_TASK_SEG) {
       if (o.b3)
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, o.ldl, M, o.Kc, 256, st,

@@ -55,7 +55,7 @@ inline int cu_count() {                              // compute units of the CUR
 // call-site tags of the GEMM launches (distinct kernel symbols for rocprofv3; profiler hook ids)
 enum GemmTag {
   TAG_GENERIC = 0, TAG_XPROJ = 1, TAG_FEAT = 2, TAG_VALUE = 3, TAG_SAMP = 4, TAG_OUTPROJ_LN = 5, TAG_FC1 = 6,
-  TAG_FC2_LN = 7, TAG_HEAD = 8, TAG_GATHER = 9, TAG_COUNT = 10
+  TAG_FC2_LN = 7, TAG_HEAD = 8, TAG_GATHER = 9, TAG_LAYER_TAIL = 10, TAG_COUNT = 11
 };
 // optional per-call-site event timing (ddp_profile_* in the C ABI); no-ops unless armed
 void prof_begin(int tag, hipStream_t st);
@@ -140,6 +140,14 @@ struct TailLaunch {
   int n_tok, w;
 };
 int launch_b3_tail(const TailLaunch& a, hipStream_t st);
+// the LAST decoder layer of a step and that step's seg tail as ONE kernel (k_layer MODE 6, ddp_layer_tail.hip): `t.Q`, the layer
+// output, never travels to HBM.  t.fuse_next as in launch_b3_tail (a next step follows) or the last step's plain tail; t.mask_sb
+// must be nullptr (u chain).  `stream` = 72 layer stages + t's stream; `bias_ext` = fc1 bias | layer 0's value_proj bias at
+// [1024, 1280); `seg_bias` = conv_seg's bias zero padded to 256 floats.  Built for 1..64 and 129..192 classes (Cityscapes, ADE):
+// b3_layer_tail_supported() says whether a class count is.
+bool b3_layer_tail_supported(int num_classes);
+int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsigned char* stream, const float* bias_ext,
+                         const float* seg_bias, hipStream_t st);
 // head of a step on the same machinery: q = W_m . m_t + xproj -> SB, then layer 0's value / sampling projections
 struct PrologueLaunch {
   const unsigned short* mask_sb;   // SB noisy map (A operand)

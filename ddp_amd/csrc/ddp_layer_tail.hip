@@ -1,0 +1,103 @@
+// ddp_layer_tail.hip - the last decoder layer of a step fused with that step's segmentation tail: k_layer MODE 6
+// (layer_bf16x3.h).  Its own translation unit: each instantiation is the whole layer kernel (FFN included) plus a tail, and the
+// four files of the library compile in parallel.
+//
+// Replaces, per step: b3::k_layer<7,0> for layer L-1 (utils/transformer.py:317-419) + b3::k_layer<8,4,NCH> (conv_seg
+// decode_head.py:133, argmax / x0 projection / DDIM update segmentors/ddp.py:235-239, softmax accumulation :241-242, the next
+// step's concat-conv :223-224 and layer 0's projections) - or + b3::k_layer<8,1,NCH> after the last step.
+#include <cstring>
+
+#include "ddp_internal.h"
+
+#include "layer_bf16x3.h"
+
+namespace ddp {
+
+namespace {
+template <int NCH, bool NT, bool FORCE>
+int launch_lt(const b3::LayerArgs& la, int grid, hipStream_t st) {
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_LAYER_TAIL, 6, NCH, NT, FORCE>), int(b3::LYR_LDS_B));
+  prof_begin(TAG_LAYER_TAIL, st);
+  hipLaunchKernelGGL((b3::k_layer<TAG_LAYER_TAIL, 6, NCH, NT, FORCE>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  prof_end(TAG_LAYER_TAIL, st);
+  return check_launch("b3::k_layer (last layer + seg tail)");
+}
+// teacher forcing (DDP_FLAG_FORCE_X0) is a test instrument: its instantiations exist without the non-temporal variant
+template <int NCH>
+int launch_lt_n(const b3::LayerArgs& la, int grid, hipStream_t st) {
+  if (la.x0_force) return launch_lt<NCH, false, true>(la, grid, st);
+  if (la.M >= b3::LYR_NT_MIN_TOKENS) return launch_lt<NCH, true, false>(la, grid, st);
+  return launch_lt<NCH, false, false>(la, grid, st);
+}
+}  // namespace
+
+bool b3_layer_tail_supported(int num_classes) {
+  const int nch = (num_classes + 63) / 64;
+  return num_classes >= 1 && (nch == 1 || nch == 3);
+}
+
+int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsigned char* stream, const float* bias_ext,
+                         const float* seg_bias, hipStream_t st) {
+  if (l.M <= 0) return DDP_OK;
+  if (!b3_layer_tail_supported(t.num_classes) || t.mask_sb || l.M != t.M || l.Q != t.Q) {
+    set_error("layer + tail kernel: unsupported call (classes %d, legacy noisy map %d)", t.num_classes, t.mask_sb ? 1 : 0);
+    return DDP_E_BADCFG;
+  }
+#if DDP_S_F32
+  if (!l.Sf) {
+    set_error("b3::k_layer: this build takes the attention output as fp32 fragments (Sf)");
+    return DDP_E_NULL;
+  }
+#endif
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  // ---- the layer (MODE 0's arguments)
+  la.S = l.S;
+  la.Sf = l.Sf;
+  la.Q = l.Q;
+  la.stream = stream;
+  la.bias_ext = bias_ext;
+  la.seg_bias = seg_bias;
+  la.bo = l.bo;
+  la.ga0 = l.ga0;
+  la.be0 = l.be0;
+  la.b2 = l.b2;
+  la.ga1 = l.ga1;
+  la.be1 = l.be1;
+  la.M = l.M;
+  // ---- the tail (MODE 1 / MODE 4's arguments)
+  la.lut = t.lut;
+  la.prob = t.prob;
+  la.x0_idx = t.x0_idx;
+  la.x0_force = t.x0_force;
+  la.num_classes = t.num_classes;
+  la.ldl = t.ldl;
+  la.prob_mode = t.prob_mode;
+  la.alpha = t.alpha;
+  la.sigma = t.sigma;
+  la.alpha_next = t.alpha_next;
+  la.sigma_next = t.sigma_next;
+  la.has_next = t.fuse_next ? 1 : 0;
+  if (t.fuse_next) {
+    // u' = ua u + uc T[argmax]:  m' = alpha' x0 + sigma' (m - alpha x0) / max(sigma, 1e-8)  (ddp.py:238-239) under W_m
+    la.ua = t.sigma_next / (t.sigma > 1e-8f ? t.sigma : 1e-8f);
+    la.uc = t.alpha_next - t.alpha * la.ua;
+    la.ubuf = t.ubuf;
+    la.tlut = t.tlut;
+    la.res = t.res;
+    la.res_rn = t.res_rn;
+    la.v_out = t.v_out;
+    la.samp_out = t.samp_out;
+    la.py = t.py;
+    la.px = t.px;
+    la.n_tok = t.n_tok;
+    la.w = t.w;
+  }
+  const int n_cu = cu_count();
+  const int tiles = (l.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  return (t.num_classes + 63) / 64 == 1 ? launch_lt_n<1>(la, grid, st) : launch_lt_n<3>(la, grid, st);
+}
+
+}  // namespace ddp

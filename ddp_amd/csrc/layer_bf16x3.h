@@ -38,6 +38,11 @@
 //   3  layer 0's projections alone (bev, ddp_head_forward) / the depth step head (one-channel concat-conv, no GEMM);
 //   4  tail of step s fused with the head of step s + 1: the DDIM update runs on u = W_m . m (affine in u and a row of
 //      the table W_m . LUT) - no concat-conv GEMM and no 256-channel noisy map after step 0.
+//   6  the LAST decoder layer of a step (MODE 0 without a next layer) + that step's tail (MODE 4, or MODE 1 after the last
+//      step: has_next = 0) in one kernel: LayerNorm1's split output IS conv_seg's operand, exactly as it feeds P3 in MODE 0,
+//      so the layer output never travels to HBM (1 KiB written + 1 KiB read per token and step) and a launch with its
+//      ring prologue / drain goes away.  One concatenated weight stream: 72 layer stages + 2 NCH conv_seg stages + 11
+//      projection stages of layer 0.
 // Where the cycles of MODE 0 go is measured, not estimated: -DDDP_LYR_STAMP builds + scripts/stamp_layer.py
 // (profiles/r02_layer_cycle_stamps*.json).
 #pragma once
@@ -56,7 +61,10 @@ constexpr int LYR_BIAS_OFF = LYR_RING * LYR_STAGE_B;
 constexpr int LYR_BIAS_N = 1024 + 256 + 128;                  // fc1 bias | next value_proj bias | zeros (sampling proj)
 // per-channel vectors kept in LDS behind the bias table (their pointers die after the kernel prologue)
 constexpr int LYR_T_BO = LYR_BIAS_N, LYR_T_GA0 = LYR_T_BO + 256, LYR_T_BE0 = LYR_T_GA0 + 256, LYR_T_B2 = LYR_T_BE0 + 256,
-              LYR_T_GA1 = LYR_T_B2 + 256, LYR_T_BE1 = LYR_T_GA1 + 256, LYR_TABLE_N = LYR_T_BE1 + 256;
+              LYR_T_GA1 = LYR_T_B2 + 256, LYR_T_BE1 = LYR_T_GA1 + 256,
+              LYR_T_SEG = LYR_T_BE1 + 256,                    // MODE 6: conv_seg's bias (tab[0..) belongs to fc1's there)
+              LYR_TABLE_N = LYR_T_SEG + 256;
+static_assert(LYR_T_SEG % 64 == 0, "bias_init addresses the table in chunks of 64 floats");
 constexpr size_t LYR_LDS_B = size_t(LYR_BIAS_OFF) + LYR_TABLE_N * 4;
 constexpr int LYR_ST_OUT = 8, LYR_ST_FFN = 64, LYR_ST_NEXT = 11;   // next: 8 value_proj + 2 + 1 (split-K) sampling stages
 constexpr int LYR_STAGES = LYR_ST_OUT + LYR_ST_FFN + LYR_ST_NEXT;
@@ -107,6 +115,9 @@ struct LayerArgs {
   // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
   // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
   const float* dvec;             // (M) noisy depth map
+  // MODE 6 (last layer + seg tail): conv_seg's bias, zero padded to 256 floats (bias_ext holds fc1's bias and, at [1024, 1280),
+  // layer 0's value_proj bias); has_next = "a next STEP follows" (MODE 4's part: u update, next q, layer 0's projections)
+  const float* seg_bias;
   // MODE 5 (stream GEMM of the necks): up to four problems in ONE persistent launch, tiles of 128 tokens numbered through all
   // of them (gp[i].tile0 = first tile of problem i; unused problems: tile0 = INT_MAX): out (fp32 fragment-major, 256 outputs)
   // = act(A . W^T), A fp32 fragment-major with 32 * ns channels (split into bf16 pieces in the filler slots, as P0 does with
@@ -375,6 +386,7 @@ k_layer(LayerArgs la) {
   int fs_tile = blockIdx.x;                                    // MODE 5: the tile whose stages are being fetched
   int n_stages = MODE == 5 ? la.gp[gp_of(int(blockIdx.x))].ns
                        : MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
+                       : MODE == 6 ? LYR_ST_OUT + LYR_ST_FFN + 2 * NCH + (la.has_next ? LYR_ST_NEXT : 0)
                                                                                     : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
@@ -518,7 +530,8 @@ k_layer(LayerArgs la) {
     if constexpr (MODE != 5)
       for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
     if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 6) tab[LYR_T_SEG + tid] = la.seg_bias[tid];
+    if constexpr (MODE == 0 || MODE == 6) {
       tab[LYR_T_BO + tid] = la.bo[tid];
       tab[LYR_T_GA0 + tid] = la.ga0[tid];
       tab[LYR_T_BE0 + tid] = la.be0[tid];
@@ -847,193 +860,6 @@ k_layer(LayerArgs la) {
       }
       continue;
     }
-    if constexpr (MODE == 1 || MODE == 4) {
-      // ---- seg tail: q fragments of this tile (the layer output), scores = conv_seg(q), per-token update
-      load_q_fragments(qf);
-      f32x16 lg[NCH > 0 ? NCH : 1][2];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        bias_init(lg[c], c);
-        tall_pair(lg[c][0], lg[c][1], I1);
-      }
-      const int m = m_base + j;
-      const bool valid = m < M;
-      const int K = la.num_classes;
-      // argmax over the token's classes: this lane holds classes 64c + 32t + 8g + 4h + e, its partner (lane ^ 32) the
-      // other half; first maximum wins (torch.argmax)
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            const float v = lg[c][t][r];
-            if (cls < K && v > best) {
-              best = v;
-              bi = cls;
-            }
-          }
-      {
-        const float ob = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bi, 32, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-          best = ob;
-          bi = oi;
-        }
-      }
-      // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
-      if (!valid || bi >= K) bi = 0;
-      if (la.x0_idx && valid && h == 0) la.x0_idx[m] = (unsigned char)bi;
-      if constexpr (FORCE) {      // teacher forcing: a test instrument in its own instantiations, the product's tails do not have it
-        if (valid) {
-          bi = la.x0_force[m];
-          if (bi >= K) bi = 0;
-        }
-      }
-      // Every global load of the epilogue is issued in a batch ahead of its consumers.  The straightforward loops (load 5,
-      // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
-      // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores
-      // too, and the LUT loads may not move above the map stores they could alias.
-      float* pr = la.prob + size_t(valid ? m : 0) * la.ldl + 4 * h;
-      char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
-      if (la.prob_mode == 1 || la.prob_mode == 2) {          // softmax over the classes, accumulated over the steps
-        float ssum = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-              const float e = cls < K ? __builtin_amdgcn_exp2f((lg[c][t][r] - best) * 1.44269504088896340736f) : 0.f;
-              lg[c][t][r] = e;
-              ssum += e;
-            }
-        ssum += __shfl_xor(ssum, 32, 64);
-        const float inv = 1.0f / ssum;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lg[c][t][r] = lg[c][t][r] * inv;
-      }
-      const bool accumulate = la.prob_mode == 2;
-      f32x4 old[NCH > 0 ? NCH : 1][2][4];
-      if (accumulate) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int cls0 = c * 64 + t * 32 + 8 * g;
-              // columns past the row (ldl >= roundup(K, 32)) are never used: read column 0 instead
-              old[c][t][g] = *reinterpret_cast<const f32x4*>(cls0 + 4 * h < K ? pr + cls0 : pr);
-            }
-      }
-      if (accumulate) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lg[c][t][r] += old[c][t][r >> 2][r & 3];
-      }
-      if (valid && la.prob_mode != 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int cls0 = c * 64 + t * 32 + 8 * g;
-              if (cls0 + 4 * h < K)                            // (rows are padded to ldl >= roundup(K, 32))
-                *reinterpret_cast<f32x4*>(pr + cls0) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
-            }
-      }
-      if constexpr (MODE == 4) {
-        // ---- the update in terms of u = W_m . m (see LayerArgs), then the NEXT step's q = (W_x x + b) + u' -> SB + fragments:
-        // per quarter of the row 8 + 8 + 8 loads (u, table row of the argmax class, x projection row) in flight
-        const float* trow = la.tlut + size_t(bi) * 256 + 4 * h;
-        float* ub = la.ubuf + grp * 8192 + lane * 4;
-        int mr = m < M ? m : M - 1;
-        const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
-        const float* rp = la.res + row * 256 + 4 * h;
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-          f32x4 uu[2][4], tt[2][4], xx[2][4];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int t = qt * 2 + i;
-              uu[i][g] = *reinterpret_cast<const f32x4*>(ub + t * 1024 + g * 256);
-              tt[i][g] = *reinterpret_cast<const f32x4*>(trow + t * 32 + 8 * g);
-              xx[i][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
-            }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int t = qt * 2 + i;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) uu[i][g][e] = la.ua * uu[i][g][e] + la.uc * tt[i][g][e];
-              *reinterpret_cast<f32x4*>(ub + t * 1024 + g * 256) = uu[i][g];
-            }
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-              const int b = 2 * t + gp;
-              float xv[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3] + uu[i][2 * gp + (e >> 2)][e & 3];
-              split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-              store_q_block(qf, b, xv);
-            }
-          }
-        }
-      } else if (la.mask_sb) {
-      // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out - two batches of eight K16 blocks:
-      // 24 + 16 loads in flight, then eight compute / store rounds (all 16 blocks at once need 320 architectural VGPRs)
-      {
-        const float* x0row = la.lut + size_t(bi) * 256 + 4 * h;
-        const float inv_sig = 1.0f / fmaxf(la.sigma, 1e-8f);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          u32x4 mk[8][3];
-          f32x4 xl[8][2];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int b = half * 8 + i;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) mk[i][c] = *reinterpret_cast<const u32x4*>(ms + (b * 3 + c) * 1024);
-            xl[i][0] = *reinterpret_cast<const f32x4*>(x0row + 16 * b);
-            xl[i][1] = *reinterpret_cast<const f32x4*>(x0row + 16 * b + 8);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int b = half * 8 + i;
-            float mn[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const float mt = (bf_elem(mk[i][0], u) + bf_elem(mk[i][1], u)) + bf_elem(mk[i][2], u);
-              const float x0 = u < 4 ? xl[i][0][u] : xl[i][1][u - 4];
-              const float pn = (mt - la.alpha * x0) * inv_sig;
-              mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
-            }
-            u32x4 q1, q2, q3;
-            split8_packed(mn, q1, q2, q3);
-            *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
-            *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
-            *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
-          }
-        }
-      }
-      }   // la.mask_sb
-    }
     if constexpr (MODE == 3) {
       if (la.res) {
         // depth step head: q = (W_x x + b)[row] + w_d * d  -> SB + fragments (no GEMM: the noisy map has one channel)
@@ -1073,12 +899,12 @@ k_layer(LayerArgs la) {
         load_q_fragments(qf);
       }
     }
-    if constexpr (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) {
-    if constexpr (MODE != 4 && MODE != 3) {
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 6) {
+    {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
     // MODE 0: the attention output arrives as fp32 fragments (la.Sf): per stage (32 channels = tile t) four quads
-    constexpr bool SF = (MODE == 0) && (DDP_S_F32 != 0);
+    constexpr bool SF = (MODE == 0 || MODE == 6) && (DDP_S_F32 != 0);
     f32x4 sf[4], sh[2];
     const float* sfp = la.Sf + grp * 8192 + lane * 4;
     if constexpr (SF) {
@@ -1095,7 +921,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == 0) b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+        if constexpr (MODE == 0 || MODE == 6) b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
       }
@@ -1229,7 +1055,7 @@ k_layer(LayerArgs la) {
         }
       }
     }
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 6) {
     // residual fragments: fetched under the last two stages
     // (fp32: 32 x 16 B per lane instead of 48 - the r02i stamps put most of P0's idle time on these two fetches: every CU
     // asks for its residual rows in the same microseconds)
@@ -1447,21 +1273,223 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
           split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-          store_q_block(qst, b, xv);
-          if (la.Q_sb) {
+          if constexpr (MODE != 6) {                  // (MODE 6: the layer output stays in xa - conv_seg's operand, the tail below)
+            store_q_block(qst, b, xv);
+            if (la.Q_sb) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qsb + (b * 3 + c) * 1024) = xa[b][c];
+              for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(qsb + (b * 3 + c) * 1024) = xa[b][c];
+            }
           }
         }
       }
     }
 
     DDP_LYR_STAMP_AT(5)                                        // LayerNorm1 + FiLM + split + q' stores
-    }   // MODE == 0
-    }   // MODE 0 / 2 only
+    }   // MODE 0 / 6
+    }   // MODE 0 / 2 / 6 only
+    }
+    if constexpr (MODE == 1 || MODE == 4 || MODE == 6) {
+      // ---- seg tail: q fragments of this tile (the layer output; MODE 6: LayerNorm1 just left them in xa), scores = conv_seg(q),
+      // per-token update
+      if constexpr (MODE == 6) refresh();
+      // fresh base (as LayerNorm1's stores above): derived from the tile-top qf, the addresses of the next q's stores would be
+      // computed at the top of the tile and kept - spilled - across the whole FFN in MODE 6
+      float* qft = la.Q + grp * 8192 + lane * 4;
+      asm volatile("" : "+v"(qft));
+      if constexpr (MODE != 6) load_q_fragments(qft);
+      f32x16 lg[NCH > 0 ? NCH : 1][2];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        bias_init(lg[c], MODE == 6 ? LYR_T_SEG / 64 + c : c);
+        tall_pair(lg[c][0], lg[c][1], I1);
+      }
+      const int m = m_base + j;
+      const bool valid = m < M;
+      const int K = la.num_classes;
+      // argmax over the token's classes: this lane holds classes 64c + 32t + 8g + 4h + e, its partner (lane ^ 32) the
+      // other half; first maximum wins (torch.argmax)
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float v = lg[c][t][r];
+            if (cls < K && v > best) {
+              best = v;
+              bi = cls;
+            }
+          }
+      {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      // padding tokens of the last group carry garbage (possibly NaN scores: no maximum found): keep the LUT row in range
+      if (!valid || bi >= K) bi = 0;
+      if (la.x0_idx && valid && h == 0) la.x0_idx[m] = (unsigned char)bi;
+      if constexpr (FORCE) {      // teacher forcing: a test instrument in its own instantiations, the product's tails do not have it
+        if (valid) {
+          bi = la.x0_force[m];
+          if (bi >= K) bi = 0;
+        }
+      }
+      // Every global load of the epilogue is issued in a batch ahead of its consumers.  The straightforward loops (load 5,
+      // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
+      // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores
+      // too, and the LUT loads may not move above the map stores they could alias.
+      float* pr = la.prob + size_t(valid ? m : 0) * la.ldl + 4 * h;
+      char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
+      if (la.prob_mode == 1 || la.prob_mode == 2) {          // softmax over the classes, accumulated over the steps
+        float ssum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int cls = c * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+              const float e = cls < K ? __builtin_amdgcn_exp2f((lg[c][t][r] - best) * 1.44269504088896340736f) : 0.f;
+              lg[c][t][r] = e;
+              ssum += e;
+            }
+        ssum += __shfl_xor(ssum, 32, 64);
+        const float inv = 1.0f / ssum;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[c][t][r] = lg[c][t][r] * inv;
+      }
+      const bool accumulate = la.prob_mode == 2;
+      f32x4 old[NCH > 0 ? NCH : 1][2][4];
+      if (accumulate) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cls0 = c * 64 + t * 32 + 8 * g;
+              // columns past the row (ldl >= roundup(K, 32)) are never used: read column 0 instead
+              old[c][t][g] = *reinterpret_cast<const f32x4*>(cls0 + 4 * h < K ? pr + cls0 : pr);
+            }
+      }
+      if (accumulate) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[c][t][r] += old[c][t][r >> 2][r & 3];
+      }
+      if (valid && la.prob_mode != 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cls0 = c * 64 + t * 32 + 8 * g;
+              if (cls0 + 4 * h < K)                            // (rows are padded to ldl >= roundup(K, 32))
+                *reinterpret_cast<f32x4*>(pr + cls0) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
+            }
+      }
+      // MODE 6 after the LAST step: nothing to update, no next head.  One uniform exit instead of two conditions (this one and
+      // P3's): with two, the allocator keeps the old xa alive - spilled - along the path that skips the update
+      if constexpr (MODE == 6) {
+        if (!la.has_next) continue;
+      }
+      if constexpr (MODE == 4 || MODE == 6) {
+        // ---- the update in terms of u = W_m . m (see LayerArgs), then the NEXT step's q = (W_x x + b) + u' -> SB + fragments:
+        // per quarter of the row 8 + 8 + 8 loads (u, table row of the argmax class, x projection row) in flight
+        const float* trow = la.tlut + size_t(bi) * 256 + 4 * h;
+        float* ub = la.ubuf + grp * 8192 + lane * 4;
+        int mr = m < M ? m : M - 1;
+        const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
+        const float* rp = la.res + row * 256 + 4 * h;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          f32x4 uu[2][4], tt[2][4], xx[2][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int t = qt * 2 + i;
+              uu[i][g] = *reinterpret_cast<const f32x4*>(ub + t * 1024 + g * 256);
+              tt[i][g] = *reinterpret_cast<const f32x4*>(trow + t * 32 + 8 * g);
+              xx[i][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
+            }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int t = qt * 2 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) uu[i][g][e] = la.ua * uu[i][g][e] + la.uc * tt[i][g][e];
+              *reinterpret_cast<f32x4*>(ub + t * 1024 + g * 256) = uu[i][g];
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const int b = 2 * t + gp;
+              float xv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] = xx[i][2 * gp + (e >> 2)][e & 3] + uu[i][2 * gp + (e >> 2)][e & 3];
+              split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+              store_q_block(qft, b, xv);
+            }
+          }
+        }
+      } else if (la.mask_sb) {
+      // x0 = LUT[argmax]; DDIM step of the noisy map (ddp.py:235-239), SB in, SB out - two batches of eight K16 blocks:
+      // 24 + 16 loads in flight, then eight compute / store rounds (all 16 blocks at once need 320 architectural VGPRs)
+      {
+        const float* x0row = la.lut + size_t(bi) * 256 + 4 * h;
+        const float inv_sig = 1.0f / fmaxf(la.sigma, 1e-8f);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          u32x4 mk[8][3];
+          f32x4 xl[8][2];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int b = half * 8 + i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mk[i][c] = *reinterpret_cast<const u32x4*>(ms + (b * 3 + c) * 1024);
+            xl[i][0] = *reinterpret_cast<const f32x4*>(x0row + 16 * b);
+            xl[i][1] = *reinterpret_cast<const f32x4*>(x0row + 16 * b + 8);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int b = half * 8 + i;
+            float mn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float mt = (bf_elem(mk[i][0], u) + bf_elem(mk[i][1], u)) + bf_elem(mk[i][2], u);
+              const float x0 = u < 4 ? xl[i][0][u] : xl[i][1][u - 4];
+              const float pn = (mt - la.alpha * x0) * inv_sig;
+              mn[u] = x0 * la.alpha_next + pn * la.sigma_next;
+            }
+            u32x4 q1, q2, q3;
+            split8_packed(mn, q1, q2, q3);
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 0) * 1024) = q1;
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 1) * 1024) = q2;
+            *reinterpret_cast<u32x4*>(ms + (b * 3 + 2) * 1024) = q3;
+          }
+        }
+      }
+      }   // la.mask_sb
+    }
+    if constexpr (MODE != 1) {
     refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
-    if (MODE == 2 || MODE == 3 || MODE == 4 || la.has_next) {
+    if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || la.has_next) {       // (MODE 6 without a next step left the tile above)
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;

@@ -72,7 +72,9 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
  * rounding (tests/test_fullsize_reference.py).  Separate kernel instantiations: the product's tails are not touched. */
 enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8,
        DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */,
-       DDP_FLAG_FORCE_X0 = 32 };
+       DDP_FLAG_FORCE_X0 = 32,
+       DDP_FLAG_UNFUSED_TAIL = 64 /* the last decoder layer of a step and the step's seg tail as the two kernels they were fused
+                                     from (identical arithmetic; same-box A/B runs, parity tests of the separate kernels) */ };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */
@@ -374,7 +376,8 @@ int ddp_sample_fcn(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_fcn
  * two threads sampling with a session armed would interleave their records): arm HIP-event timing
  * around every launch of one GEMM call site, then read the summed duration and launch count.
  * tag: 1 xproj, 2 feat / step prologue, 3 value_proj, 4 sampling proj, 5 output_proj+LN, 6 FFN fc1, 7 FFN fc2+LN / the
- * layer kernel, 8 head conv / seg tail, 9 deformable gather; 255 = all of them at once.  ddp_profile_end synchronises on
+ * layer kernel, 8 head conv / seg tail, 9 deformable gather, 10 last layer of a step + seg tail (one kernel); 255 = all of
+ * them at once.  ddp_profile_end synchronises on
  * the recorded events and returns the sum over all records; ddp_profile_read then gives one call site's share
  * (DDP_E_BADCFG for an unknown tag or when no finished session exists). */
 int ddp_profile_begin(int tag);

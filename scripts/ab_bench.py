@@ -24,7 +24,7 @@ from ddp_amd.engine import DDPEngine, PackedWeights  # noqa: E402
 from ddp_amd.utils import synthetic  # noqa: E402
 import bench  # noqa: E402
 
-TAGS = {2: 'prologue', 7: 'layer', 8: 'tail', 9: 'gather', 1: 'xproj'}
+TAGS = {2: 'prologue', 7: 'layer', 8: 'tail', 9: 'gather', 1: 'xproj', 10: 'layer_tail'}
 
 
 def main():

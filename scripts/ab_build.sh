@@ -15,7 +15,7 @@ for ref in "$@"; do
   git -C "$ROOT" archive "$ref" ddp_amd/csrc include | tar -x -C "$tmp"
   mkdir -p "$ROOT/ddp_amd/$name"
   ( cd "$tmp/ddp_amd/csrc"
-    for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels; do
+    for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels ddp_layer_tail; do
       /opt/rocm/bin/hipcc $FLAGS -x hip -c $f.hip -o "$tmp/$f.o" &
     done
     wait

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Cycle accounting of the layer kernel (b3::k_layer MODE 0) with a -DDDP_LYR_STAMP build of the library:
 
-  cd ddp_amd/csrc && for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels; do \\
+  cd ddp_amd/csrc && for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels ddp_layer_tail; do \\
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DDDP_LYR_STAMP=1 -x hip -c $f.hip -o /tmp/st_$f.o; done
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_stamp/libddp_mi355x.so /tmp/st_*.o
   python scripts/stamp_layer.py            # on the GPU box

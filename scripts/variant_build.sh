@@ -7,7 +7,7 @@ name=lib_$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $*"
 mkdir -p "$ROOT/ddp_amd/$name"
 cd "$ROOT/ddp_amd/csrc"
-for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels; do
+for f in ddp_api ddp_gemm ddp_gemm_bf16 ddp_kernels ddp_layer_tail; do
   /opt/rocm/bin/hipcc $FLAGS -x hip -c $f.hip -o "$ROOT/ddp_amd/$name/$f.o" &
 done
 wait

@@ -240,6 +240,8 @@ def test_head_forward_trace(dev, name):
 VARIANTS = {'bf16x3': dict(gemm='bf16x3'), 'f32': dict(gemm='f32'),
             'bf16x3-unfused-layer': dict(gemm='bf16x3', fused_layer=False),
             'bf16x3-unfused-prologue': dict(gemm='bf16x3', fused_prologue=False),
+            # the last layer of a step and the seg tail as the two kernels they were fused from (DDP_FLAG_UNFUSED_TAIL)
+            'bf16x3-unfused-tail': dict(gemm='bf16x3', fused_tail=False),
             # the LDS gather's "actual mean offset is far from the guess: refill the window" branch (DDP_FLAG_GATHER_GUESS_ZERO)
             'bf16x3-gather-refill': dict(gemm='bf16x3', gather_guess_zero=True)}
 

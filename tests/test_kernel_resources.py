@@ -36,6 +36,26 @@ def test_layer_kernels_have_no_scratch(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+def test_layer_tail_kernels_have_no_scratch(tmp_path):
+    """k_layer MODE 6 (last layer of a step + seg tail, its own translation unit): the whole layer kernel plus a tail in one
+    function body - the allocator must still keep every phase in the 512 registers (two spill sources were removed by hand:
+    the next q's store addresses derived at the top of the tile, and a second exit condition that kept the old fragments alive)"""
+    out = tmp_path / 'layer_tail.s'
+    src = os.path.join(ROOT, 'ddp_amd', 'csrc', 'ddp_layer_tail.hip')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-x', 'hip', src,
+                    '--cuda-device-only', '-S', '-o', str(out)], check=True, capture_output=True, timeout=600)
+    found = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', out.read_text(), re.S):
+        if 'k_layer' not in m.group(1):
+            continue
+        found += 1
+        body = m.group(2)
+        assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0, m.group(1)
+        assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 512
+    assert found == 6          # {1..64, 129..192 classes} x {plain, non-temporal, teacher-forced}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
 def test_gather_fits_three_blocks_per_cu(tmp_path):
     """the LDS-staged gather overlaps fill and taps ACROSS blocks (three 512-thread blocks per CU = 6 waves per SIMD): no
     scratch, <= 85 registers, and a window + bookkeeping of at most 160 KiB / 3 of LDS"""
