@@ -88,6 +88,122 @@ def usable_cores():
     return n
 
 
+def plan_affinity(allowed, world, local_rank, quota=None, numa_of_rank=None, node_cpus=None):
+    """The cores rank ``local_rank`` of ``world`` pins itself (and so its data-loader workers and torch's intra-op threads) to.
+    The sampler has no collective, so what N ranks share is the HOST: the measurement of round 4 (``--host-leg``) has the B = 1
+    rate unchanged with seven busy neighbours but 24-31 % lower once the node is oversubscribed - a rank whose launch thread is
+    descheduled in favour of another rank's loader worker stalls its GPU.  Disjoint core sets rule that out (the reference's
+    launcher, tools/dist_test.sh:10-20, leaves placement to the OS).
+      allowed       the process's affinity mask (os.sched_getaffinity), any iterable of core ids
+      quota         cgroup cpu quota in cores (cpu.max), or None: with fewer cores than the mask shows, every rank still gets a
+                    DISJOINT set, but only ``quota // world`` (at least 1) of them
+      numa_of_rank  optional list: NUMA node of every local rank's GPU; node_cpus: {node: iterable of core ids}.  When both are
+                    known a rank only takes cores of its GPU's node, split among the ranks of that node; otherwise the mask is
+                    split evenly in rank order.
+    Pure function (tests/test_host_logic.py); returns a sorted list, never empty for a non-empty mask."""
+    allowed = sorted(set(int(c) for c in allowed))
+    world = max(1, int(world))
+    if not allowed:
+        return []
+    pool, peers, me = allowed, world, int(local_rank)
+    if numa_of_rank is not None and node_cpus is not None and len(numa_of_rank) == world:
+        # the decision is the same on every rank: NUMA-aware only when EVERY node has at least one allowed core per rank of
+        # its GPUs (a mixed plan would hand the same core to two ranks)
+        def cores_of(node):
+            return sorted(set(int(c) for c in node_cpus.get(node, ())) & set(allowed))
+        nodes = set(numa_of_rank)
+        if all(n is not None and n >= 0 and len(cores_of(n)) >= sum(1 for x in numa_of_rank if x == n) for n in nodes):
+            node = numa_of_rank[me]
+            same = [r for r in range(world) if numa_of_rank[r] == node]
+            pool, peers, me = cores_of(node), len(same), same.index(me)
+    per = len(pool) // peers
+    if per == 0:                              # more ranks than cores: share, round-robin
+        return [pool[me % len(pool)]]
+    chunk = pool[me * per:(me + 1) * per]
+    if quota is not None:
+        chunk = chunk[:max(1, min(len(chunk), int(quota) // world))]
+    return chunk
+
+
+def strong_share(workload, world, call_batch):
+    """--scaling strong: a rank's share of the configuration's TOTAL batch (BASELINE.json) -> (images per call, calls per step).
+    C2: 8 images -> 1 per rank at 8 GPUs; C3: 32 -> 4; C4: 16 -> 2; C5: 64 -> 8.  Images are independent (the reference's sampler
+    is one image per call anyway), a share larger than the workload's call batch runs as several calls."""
+    if workload not in TOTAL_BATCH:
+        raise SystemExit(f'bench.py: --scaling strong needs a BASELINE configuration, one of {sorted(TOTAL_BATCH)}')
+    total = TOTAL_BATCH[workload]
+    if total % world:
+        raise SystemExit(f'bench.py: total batch {total} of {workload} does not split over {world} ranks')
+    share = total // world
+    b = min(share, call_batch)
+    if share % b:
+        raise SystemExit(f'bench.py: per-rank share {share} is not a multiple of the call batch {b}')
+    return b, share // b
+
+
+def gather_rank_stats(elapsed, step_ms, images_per_rank_step, steps, dev):
+    """every rank's own clock and step times -> (per_rank dict, MAX elapsed over ranks) on every rank.  A straggler must be
+    visible in the line, not averaged away; the contract's figure is the MAX.  Needs an initialised process group."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = torch.tensor([elapsed, sum(step_ms) / len(step_ms), min(step_ms), max(step_ms)], dtype=torch.float64, device=dev)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    rows = [[float(v) for v in g.tolist()] for g in got]
+    per_rank = {'elapsed_s': [round(r[0], 4) for r in rows],
+                'images_per_s': [round(images_per_rank_step * steps / r[0], 2) for r in rows],
+                'step_ms_mean': [round(r[1], 3) for r in rows],
+                'step_ms_min_over_ranks': round(min(r[2] for r in rows), 3), 'step_ms_max_over_ranks': round(max(r[3] for r in rows), 3),
+                'slowest_rank': max(range(world), key=lambda i: rows[i][0])}
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return per_rank, float(t.item())
+
+
+def _gpu_numa_nodes(world):
+    """NUMA node of every visible GPU (sysfs), and the cores of every node; (None, None) when the box does not say."""
+    try:
+        nodes = []
+        for i in range(world):
+            bdf = torch.cuda.get_device_properties(i).pci_bus_id if hasattr(torch.cuda.get_device_properties(i), 'pci_bus_id') else None
+            if bdf is None:
+                return None, None
+            nodes.append(int(open(f'/sys/bus/pci/devices/{bdf.lower()}/numa_node').read()))
+        cpus = {}
+        for n in set(nodes):
+            if n < 0:
+                return None, None
+            ids = []
+            for part in open(f'/sys/devices/system/node/node{n}/cpulist').read().strip().split(','):
+                a, _, b = part.partition('-')
+                ids += list(range(int(a), int(b or a) + 1))
+            cpus[n] = ids
+        return nodes, cpus
+    except Exception:
+        return None, None
+
+
+def pin_rank(local_rank, world):
+    """apply plan_affinity to this process; -> what was done (for the JSON line).  Never fatal."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        quota = None
+        try:
+            q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+            if q != 'max':
+                quota = max(1, int(int(q) / int(p)))
+        except Exception:
+            pass
+        nodes, cpus = _gpu_numa_nodes(world)
+        mine = plan_affinity(allowed, world, local_rank, quota, nodes, cpus)
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, len(mine)))
+        return {'cores': len(mine), 'first_core': mine[0], 'last_core': mine[-1], 'mask_cores': len(allowed), 'cgroup_quota_cores': quota,
+                'numa_aware': nodes is not None, 'gpu_numa_node': None if nodes is None else nodes[local_rank]}
+    except Exception as e:
+        return {'error': str(e)[:160]}
+
+
 def require_devices(n):
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < n:
@@ -511,6 +627,12 @@ def main():
                     help='also measure host enqueue time per sample() call, plain and as a hipGraph, and the B = 1 rate with the '
                          'host busy (other ranks + data loaders modelled by busy processes); reported under "host"')
     ap.add_argument('--host-seconds', type=float, default=2.0)
+    ap.add_argument('--weights', choices=sorted(synthetic.PROFILES), default='init',
+                    help="weight profile of the headline number (ddp_amd/utils/synthetic.py PROFILES).  'init' (default): the reference's "
+                         "initialisation + small perturbations.  'trained_like': content-dependent sampling offsets of +- 2.4 px - what "
+                         'real checkpoints are more likely to look like; the default line carries its rate as the "trained_like" sub-record')
+    ap.add_argument('--no-trained-like', action='store_true', help='skip the trained_like sub-record of the default line')
+    ap.add_argument('--no-pin', action='store_true', help='N > 1: do not pin the ranks to disjoint core sets')
     ap.add_argument('--next-rows', action='store_true',
                     help='also time the rows either side of the loop on the same batch (SURVEY.md §8 f1/f2): FPN + '
                          'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
@@ -534,6 +656,8 @@ def main():
                          f'(or run `python bench.py --gpus {args.gpus}` without a rendezvous environment)')
     require_devices(world)
     dist_on = world > 1 or args.force_dist
+    # N > 1: every rank (and the loader workers / intra-op threads it spawns) on its own cores, near its GPU when the box says
+    pinned = pin_rank(local_rank, world) if (world > 1 and not args.no_pin) else None
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
@@ -548,21 +672,12 @@ def main():
     # batch (images are independent: the reference's sampler is one image per call anyway)
     calls_per_step = 1
     if args.scaling == 'strong':
-        if args.workload not in TOTAL_BATCH:
-            raise SystemExit(f'bench.py: --scaling strong needs a BASELINE configuration, one of {sorted(TOTAL_BATCH)}')
-        total = TOTAL_BATCH[args.workload]
-        if total % world:
-            raise SystemExit(f'bench.py: total batch {total} of {args.workload} does not split over {world} ranks')
-        share = total // world
-        B = min(share, wl['batch'])
-        if share % B:
-            raise SystemExit(f'bench.py: per-rank share {share} is not a multiple of the call batch {B}')
-        calls_per_step = share // B
+        B, calls_per_step = strong_share(args.workload, world, wl['batch'])
     # frozen weights: generated on rank 0, replicated by ONE RCCL broadcast of the packed blob
     task = wl['task']
     cx = wl.get('feat_channels', 256)
     cm = 1 if task == 'depth' else 256
-    sd = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2)
+    sd = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2, profile=args.weights)
     weights = PackedWeights(sd, task, wl['num_layers'], dev)
     if dist_on:
         if rank != 0:
@@ -609,10 +724,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    per_rank = None
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        per_rank, elapsed = gather_rank_stats(elapsed, step_ms, B * calls_per_step, args.steps, dev)
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = B * calls_per_step * world * args.steps / elapsed
 
@@ -664,12 +778,20 @@ def main():
             # + next layer's value_proj 2*256*256 and sampling projection 2*256*96 for all but the last layer;
             # averaged over the L launches of a step
             L = wl['num_layers']
-            per_tok = (L * (2 * 256 * 256 + 4 * 256 * 1024) + (L - 1) * (2 * 256 * 256 + 2 * 256 * 96)) / L
+            full = 2 * 256 * 256 + 4 * 256 * 1024 + 2 * 256 * 256 + 2 * 256 * 96          # 1 359 872 flop per token
+            per_step = n.value / float(reps * K * calls_per_step)                          # launches of this call site per step
+            if abs(per_step - (L - 1)) < 1e-6:
+                # the LAST layer of a step runs fused with the step's tail under its own call site (k_layer MODE 6, tag 10): every
+                # launch counted here is a whole layer with the next layer's projections
+                per_tok = full
+                note = f'the {L - 1} launches per step that are followed by another layer; the last layer runs fused with the seg tail'
+            else:
+                per_tok = (L * (2 * 256 * 256 + 4 * 256 * 1024) + (L - 1) * (2 * 256 * 256 + 2 * 256 * 96)) / L
+                note = 'flops averaged over the L launches of a step'
             flops_launch = per_tok * M
             peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
             kernel = ('b3::k_layer<7> (persistent: output_proj+LN0, FFN fc1+GELU+fc2+LN1+FiLM, next value/sampling proj; '
-                      'fp32 products as 6 bf16 MFMA products, peak = 2500 TFLOP/s dense bf16 / 6; flops averaged over '
-                      'the L launches of a step)')
+                      'fp32 products as 6 bf16 MFMA products, peak = 2500 TFLOP/s dense bf16 / 6; ' + note + ')')
         elif eng.gemm == 'bf16x3':
             flops_launch = 2.0 * 256 * 1024 * M
             peak = BF16_MFMA_PEAK_TFLOPS / B3_PRODUCTS
@@ -722,6 +844,47 @@ def main():
         roofline['loop_frac'] = round(roofline['loop_tflops'] / peak, 4)
         if rank == 0 and not args.no_power and eng.gemm == 'bf16x3':
             roofline['same_box_vendor_gemm'] = vendor_gemm_reference(dev, local_rank)
+
+    # ---- the same workload on the trained-like weight profile: the headline runs on the reference's
+    # initialisation (offsets on the per-head ring +- 0.3 px), real checkpoints are more likely to spread the offsets with the
+    # content - the LDS-staged gather then serves more taps from outside its window.  Rank 0, same inputs, its own engine.
+    trained = None
+    if rank == 0 and task == 'seg' and args.weights == 'init' and not args.no_trained_like:
+        try:
+            lib = _lib.load()
+            sd_t = synthetic.make_state_dict(task, wl['num_classes'], wl['num_layers'], cx, seed=2, profile='trained_like')
+            eng_t = DDPEngine(sd_t, task, **dict(kw, weights=PackedWeights(sd_t, task, wl['num_layers'], dev)))
+            out_t = torch.empty_like(out)
+
+            def gather_ms(e, o):
+                _lib.check(lib.ddp_profile_begin(9))
+                e.sample(dx, dn, out=o)
+                tt, nn = C.c_float(0), C.c_int(0)
+                _lib.check(lib.ddp_profile_end(C.byref(tt), C.byref(nn)))
+                return tt.value / max(nn.value, 1)
+            eng_t.sample(dx, dn, out=out_t)
+            torch.cuda.synchronize()
+            reps_t = max(3, min(args.steps, 10))
+            tt0 = time.perf_counter()
+            for _ in range(reps_t):
+                eng_t.sample(dx, dn, out=out_t)
+            torch.cuda.synchronize()
+            ms_t = (time.perf_counter() - tt0) / reps_t * 1e3
+            # the init profile again, back to back in the same seconds (the timed region above ran before the power leg)
+            tt0 = time.perf_counter()
+            for _ in range(reps_t):
+                eng.sample(dx, dn, out=out)
+            torch.cuda.synchronize()
+            ms_i = (time.perf_counter() - tt0) / reps_t * 1e3
+            trained = {'images_per_s': round(B / ms_t * 1e3, 2), 'ms_per_step': round(ms_t, 3),
+                       'init_images_per_s_back_to_back': round(B / ms_i * 1e3, 2), 'penalty': round(1.0 - ms_i / ms_t, 4),
+                       'gather_ms': round(gather_ms(eng_t, out_t), 4), 'gather_ms_init': round(gather_ms(eng, out), 4),
+                       'finite': bool(torch.isfinite(out_t).all()),
+                       'note': "weights = synthetic.PROFILES['trained_like'] (content-dependent offsets +- 2.4 px, peaked attention, 8x "
+                               'class scores); same inputs, one call per step; never part of value'}
+            del eng_t, out_t
+        except Exception as e:                                       # reported, never fatal for the bench line
+            trained = {'error': str(e)[:200]}
 
     # ---- rows either side of the loop (optional, rank 0): the neck that produces x, the epilogue that consumes out --
     next_rows = None
@@ -882,7 +1045,8 @@ def main():
                        'images_per_gpu_per_step': B * calls_per_step, 'images_per_call': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
             'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
-            'images_per_s_per_gpu': round(images_per_s / world, 3),
+            'images_per_s_per_gpu': round(images_per_s / world, 3), 'per_rank': per_rank, 'affinity': pinned,
+            'weights_profile': args.weights, 'trained_like': trained,
             'step_ms': {'mean': round(sum(step_ms) / len(step_ms), 3), 'min': round(min(step_ms), 3), 'max': round(max(step_ms), 3),
                         'std': round((sum((t - sum(step_ms) / len(step_ms)) ** 2 for t in step_ms) / len(step_ms)) ** 0.5, 3),
                         'source': 'HIP events between the steps of the timed region (rank 0)'},

@@ -146,3 +146,74 @@ def test_multi_gpu_test_gloo(tmp_path):
     assert r0['gpu'] == list(range(7)) and r1['gpu'] is None and r0['rescale'] and r1['rescale']
     assert r0['cpu'] == [(i, i * 24) for i in range(7)] and r1['cpu'] is None
     assert r0['fmt'] == [f'f{i}' for i in range(7)] and r1['fmt'] is None
+
+
+# ---- world 8: the 8-GPU node is never available to the builder - the relaunch path's arithmetic, the
+# per-rank statistics of the bench line, the core pinning and the harness's result collection run here with EIGHT gloo ranks
+def _world8_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    from ddp_amd import apis, parallel
+    out = {}
+    # (a) the strong-scaling shares of the BASELINE configurations (bench.py --scaling strong), and a ragged total through the
+    # shard / gather helpers: C2 8 -> 1 per rank, C5 64 -> 8, 13 images -> 2,2,2,2,2,1,1,1
+    out['c2'] = bench.strong_share('ade_swin_t_k3_8x512x1024', world, 8)
+    out['c3'] = bench.strong_share('city_swin_l_k10_4x1024x2048', world, 4)
+    out['c4'] = bench.strong_share('kitti_depth_k20_16x352x1216', world, 16)
+    out['c5'] = bench.strong_share('bev_fusion_k3_8x200x200', world, 8)
+    for total in (8, 64, 13):
+        x = torch.arange(total * 3, dtype=torch.float32).reshape(total, 3)
+
+        class FakeEngine:
+            def sample(self, xs, ns):
+                return xs * 3 - ns
+
+        o, (a, b) = parallel.sample_sharded(lambda n: FakeEngine(), x, torch.ones_like(x))
+        full = parallel.gather_outputs(o, total)
+        out[f'gather{total}'] = bool(torch.equal(full, x * 3 - 1)) and (a, b) == parallel.shard_range(total, rank, world)
+        out[f'shard{total}'] = b - a
+    # (b) the bench line's per-rank statistics: rank 5 is the straggler
+    elapsed = 1.0 + (0.5 if rank == 5 else 0.0) + 0.001 * rank
+    per_rank, mx = bench.gather_rank_stats(elapsed, [10.0 + rank, 11.0 + rank], 1, 2, torch.device('cpu'))
+    out['per_rank'], out['max_elapsed'] = per_rank, mx
+    # (c) pinning: the ranks' core sets must be pairwise disjoint whenever the mask has at least one core per rank
+    before = sorted(os.sched_getaffinity(0))
+    pin = bench.pin_rank(rank, world)
+    out['pin'] = pin
+    out['mask'] = sorted(os.sched_getaffinity(0))
+    out['before'] = before
+    # (d) multi_gpu_test over 8 ranks, 19 samples (the sampler repeats 5), both collection modes
+    ds = _ToyDataset(19)
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, sampler=sampler, collate_fn=_toy_collate)
+    r = apis.multi_gpu_test(_ToyModel(), loader, gpu_collect=True)
+    out['gpu'] = None if r is None else [int(a[0, 0]) for a in r]
+    out['cpu'] = apis.multi_gpu_test(_ToyModel(), loader, tmpdir=os.path.join(tmp, 'collect8'), pre_eval=True)
+    torch.save(out, os.path.join(tmp, f'w{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_relaunch_arithmetic_stats_pinning_and_collection(tmp_path):
+    world = 8
+    port = 30300 + os.getpid() % 300
+    mp.spawn(_world8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f'w{r}.pt'), weights_only=False) for r in range(world)]
+    for r in res:
+        assert r['c2'] == (1, 1) and r['c3'] == (4, 1) and r['c4'] == (2, 1) and r['c5'] == (8, 1)
+        assert r['gather8'] and r['gather64'] and r['gather13']
+    assert [r['shard8'] for r in res] == [1] * 8 and [r['shard64'] for r in res] == [8] * 8
+    assert [r['shard13'] for r in res] == [2, 2, 2, 2, 2, 1, 1, 1]
+    pr = res[0]['per_rank']
+    assert pr == res[7]['per_rank'] and pr['slowest_rank'] == 5 and abs(res[3]['max_elapsed'] - 1.505) < 1e-9
+    assert pr['images_per_s'][5] < pr['images_per_s'][4] and pr['step_ms_min_over_ranks'] == 10.0 and pr['step_ms_max_over_ranks'] == 18.0
+    masks = [set(r['mask']) for r in res]
+    assert all('error' not in r['pin'] for r in res), [r['pin'] for r in res]
+    if len(res[0]['before']) >= world:
+        assert all(not (masks[i] & masks[j]) for i in range(world) for j in range(i + 1, world)), masks
+    assert all(m and m <= set(res[0]['before']) for m in masks)
+    assert res[0]['gpu'] == list(range(19)) and all(r['gpu'] is None for r in res[1:])
+    assert res[0]['cpu'] == [(i, i * 24) for i in range(19)] and all(r['cpu'] is None for r in res[1:])

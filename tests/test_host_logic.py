@@ -608,3 +608,24 @@ def test_learned_sinusoidal_dim_guard():
         with pytest.raises(ValueError, match='learned_sinusoidal_dim'):
             make(8)
     BevDDP(learned_sinusoidal_dim=16)
+
+
+def test_plan_affinity_disjoint_quota_and_numa():
+    """bench.py's core plan for N > 1: disjoint sets in rank order; a cgroup quota smaller than the mask
+    shrinks every set but keeps them disjoint; with the GPUs' NUMA nodes known a rank only takes cores of its GPU's node; more
+    ranks than cores share round-robin instead of failing."""
+    import bench
+    sets = [bench.plan_affinity(range(64), 8, r) for r in range(8)]
+    assert all(len(s) == 8 for s in sets) and sorted(sum(sets, [])) == list(range(64))
+    sets = [bench.plan_affinity(range(256), 8, r, quota=16) for r in range(8)]
+    assert all(len(s) == 2 for s in sets) and len(set(sum(sets, []))) == 16
+    assert [bench.plan_affinity(range(4), 8, r) for r in range(8)] == [[0], [1], [2], [3], [0], [1], [2], [3]]
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    sets = [bench.plan_affinity(range(192), 8, r, None, numa, cpus) for r in range(8)]
+    assert all(set(s) <= set(cpus[numa[r]]) and len(s) == 24 for r, s in enumerate(sets))
+    assert len(set(sum(sets, []))) == 192
+    # a node without enough cores in the mask for its ranks: fall back to the plain even split
+    sets = [bench.plan_affinity(range(16), 8, r, None, numa, {0: [0, 1], 1: range(2, 16)}) for r in range(8)]
+    assert sorted(sum(sets, [])) == list(range(16))
+    assert bench.plan_affinity([], 8, 0) == [] and bench.plan_affinity([5], 1, 0) == [5]
