@@ -387,6 +387,16 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 #ifndef DDP_GL_V
 #define DDP_GL_V 2
 #endif
+// window halo of the product launch (launch_msda_gather_sb_pad): 3 -> 23 x 15 px = 44 KiB, three blocks per CU.  Round 5, same
+// box (profiles/r05c_ab_gather_*.txt; ms per launch at C2, init / trained_like weight profile): halo 3 0.151 / 0.230; halo 5
+// (64 KiB, two blocks per CU) 0.200 / 0.274; halo 6 (77 KiB) 0.209 / 0.254 - with content-dependent offsets of +- 2.4 px
+// nearly every 8-token group has SOME corner outside even a +-6 px window, so a larger window only costs occupancy.  The mixed
+// path itself with the four points unrolled on DPP broadcasts: hipcc spills in the divergent region at the 85 registers three
+// blocks per CU allow; the same through flat loads (per-lane address = shared aperture or global, one instruction stream, 80
+// registers, no spill) 0.149 / 0.254 - slower than the rolled ds_bpermute loop below on the profile it was meant for.
+#ifndef DDP_GL_HALO
+#define DDP_GL_HALO 3
+#endif
 
 // sum over the 64 lanes by DPP: quad permutes, row_half_mirror, row_mirror (every lane of a row of 16 holds the row's sum),
 // row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 - lanes 48..63 hold the total
@@ -1962,11 +1972,11 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
   if (out_f32_blk)
-    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT, true>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp,
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_HALO <= 3 ? 6 : 4, NT, true>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp,
                        reinterpret_cast<unsigned short*>(out_f32_blk), n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x,
                        zero_guess);
   else
-    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, 3, 4, NT, false>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_HALO <= 3 ? 6 : 4, NT, false>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
                        n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");
