@@ -328,7 +328,8 @@ __device__ constexpr int SPLIT_HAND_LO[13] = {0, 3, 6, 10, 14, 17, 20, 24, 29, 3
 // into the product library.
 #ifdef DDP_LYR_STAMP
 constexpr int LYR_NSTAMP = 16;
-#define DDP_LYR_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[LYR_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DDP_LYR_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[LYR_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #define DDP_LYR_STAMP_AT(i)                                   \
   {                                                           \
     const unsigned long long st_now = __builtin_readcyclecounter(); \
@@ -1575,8 +1576,17 @@ k_layer(LayerArgs la) {
     }
   }
 #ifdef DDP_LYR_STAMP
-  if (la.stamps && (threadIdx.x & 63) == 0)
+  if (la.stamps && (threadIdx.x & 63) == 0) {
     for (int i = 0; i < LYR_NSTAMP; ++i) la.stamps[(size_t(blockIdx.x) * 4 + wave) * LYR_NSTAMP + i] += st_acc[i];   // summed over launches
+    // per-XCD completion skew (scripts/xcd_skew.py): the 100 MHz chip-wide clock at the start and the end of this wave's share of
+    // the LAST launch, and the XCD it ran on (slots 8, 14, 15 carry no phase)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* row = la.stamps + (size_t(blockIdx.x) * 4 + wave) * LYR_NSTAMP;
+    row[8] = st_t0;
+    row[14] = __builtin_amdgcn_s_memrealtime();
+    row[15] = xcc & 0xF;
+  }
 #endif
 #undef DDP_LYR_BLOCK
 #undef DDP_LYR_BLOCK2

@@ -70,14 +70,14 @@ def vendor_gemm(m, n, k, seconds, dev):
     return rec
 
 
-def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0, dma=0, hbm=0):
+def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0, dma=0, hbm=0, share=0):
     exe = os.path.join(ROOT, 'scripts', 'ubench', 'mfma_chip')
     if not os.path.exists(exe):
         return {'error': 'scripts/ubench/mfma_chip not built (hipcc --offload-arch=gfx950 -O2 mfma_chip.hip -o mfma_chip)'}
     ps = bench.PowerSampler()
     ps.start()
     t0 = time.perf_counter()
-    p = subprocess.run([exe, str(wps), str(chains), str(seconds), str(pattern), str(ldsr), str(valu), str(dma), str(hbm)], capture_output=True,
+    p = subprocess.run([exe, str(wps), str(chains), str(seconds), str(pattern), str(ldsr), str(valu), str(dma), str(hbm), str(share)], capture_output=True,
                        text=True, timeout=120)
     t1 = time.perf_counter()
     ps.stop()
@@ -91,6 +91,8 @@ def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0, dma=0, hbm=0):
         rec.update(power_w=pw['power_w'], sclk_mhz=pw['sclk_mhz'])
         if pw['sclk_mhz']:
             rec['cycles_per_mfma'] = round(pw['sclk_mhz'] * 1e6 / rec['mfma_per_simd_per_s'], 2)
+        # the part sits at its cap in every leg, so the rate of a leg IS its energy per instruction
+        rec['nj_per_wave_mfma'] = round(pw['power_w'] / (rec['tflops_bf16'] * 1e12 / 32768.0) * 1e9, 2)
     return rec
 
 
@@ -136,6 +138,9 @@ def main():
     ap.add_argument('--components', action='store_true',
                     help='only the attribution table of VERDICT r03 next #4: the layer kernel, then the MFMA + LDS-read + VALU mix alone, '
                          '+ the LDS-DMA weight stream, + the HBM fragment streams (one box, one process, watts and MHz beside each)')
+    ap.add_argument('--operand-sharing', action='store_true',
+                    help='only VERDICT r04 next #6 (i): nJ per MFMA when consecutive MFMAs share their A / their B / both operands '
+                         '(scripts/ubench/mfma_chip.hip, registers only)')
     ap.add_argument('--caps', default='1200,1000', help='package power caps (W) for the sweep')
     ap.add_argument('--clocks', default='1500', help='shader clock limits (MHz) for the sweep')
     args = ap.parse_args()
@@ -153,6 +158,16 @@ def main():
     torch.cuda.synchronize()
     res = {'headline': headline(eng, dx, dn, out, wl['batch'], args.seconds)}
     print('headline', json.dumps(res['headline']), file=sys.stderr, flush=True)
+    if args.operand_sharing:
+        res['operand_sharing'] = []
+        for name, sh in (('rotation (A every 2nd, B every MFMA)', 0), ('A shared by 3 consecutive MFMAs', 1), ('B shared by 3 consecutive MFMAs', 2),
+                         ('A and B never change', 3), ('rotation (again: drift check)', 0)):
+            rec = mfma_chip(1, 2, 1, args.seconds, share=sh)
+            rec['leg'] = name
+            res['operand_sharing'].append(rec)
+            print(name, json.dumps(rec), file=sys.stderr, flush=True)
+        print(json.dumps(res))
+        return
     if args.components:
         legs = [('mfma_only', (0, 0, 0, 0)), ('mix', (1, 3, 0, 0)), ('mfma+dma', (0, 0, 1, 0)), ('mix+dma', (1, 3, 1, 0)),
                 ('mix+dma+hbm', (1, 3, 1, 1)), ('mix (again)', (1, 3, 0, 0))]

@@ -4,6 +4,12 @@
 // part does not hold it while the matrix pipes are busy.  This loop measures that ceiling directly:
 //   mfma_chip <waves per SIMD: 1|2> <accumulator chains per wave: 2|4> <seconds> [operand pattern: 0 zeros | 1 random bits]
 //             [ds_read_b128 per two MFMAs: 0|1|2] [fp32 VALU fillers per MFMA: 0|2|3|4] [weight stream by LDS-DMA: 0|1] [HBM streams: 0|1]
+//             [operand sharing: 0|1|2|3]
+// Round 5: does it matter, in joules per MFMA, WHICH operands consecutive MFMAs share?  Registers only,
+// two accumulator chains, random operand bits:  0 = the rotation above (A changes every 2nd MFMA, B every MFMA);  1 = three
+// consecutive MFMAs share their A registers (the layer kernel's "same weight fragment x the three activation pieces", issued
+// back to back), B changes every MFMA;  2 = three consecutive share B, A changes every MFMA;  3 = every MFMA reads the same A and
+// the same B (random bits that never change: what the datapath costs when no input toggles).
 // The last two add what the layer kernel does around its MFMAs - the A fragments come out of LDS (random bits, a different
 // KiB every read) and independent v_fma_f32 fill the issue slots behind each MFMA - still without any global memory: how
 // much clock do those cost at the cap?
@@ -26,7 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <int CHAINS, int LDSR, int VALU, int DMA = 0, int HBM = 0>
+template <int CHAINS, int LDSR, int VALU, int DMA = 0, int HBM = 0, int SHARE = 0>
 __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc, int iters, int pattern, const u32x4* wstream,
                                             const u32x4* hbm_in, u32x4* hbm_out) {
   extern __shared__ u32x4 lds[];                          // 48 KiB stage image read by the fragments (+ 96 KiB more = the 3-slot ring with DMA)
@@ -121,7 +127,11 @@ __global__ void __launch_bounds__(512, 1) k(float* sink, unsigned long long* cyc
         const unsigned addr = lds_base + (((unsigned(it) * 16u + u) * 64u + lane) & 2047u) * 16u     /* (a power of two: no integer division in the loop) */;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(3)" : "=v"(a[(u / CHAINS + 2) & 3]) : "v"(addr));
       }
-      acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(u / CHAINS) & 3]), __builtin_bit_cast(bf16x8, b[(u / CHAINS + u) & 3]), acc[u % CHAINS], 0, 0, 0);
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int ai = SHARE == 0 ? (u / CHAINS) & 3 : SHARE == 1 ? (u / 3) & 3 : SHARE == 2 ? u & 3 : 0;
+      const int bi = SHARE == 0 ? (u / CHAINS + u) & 3 : SHARE == 1 ? u & 3 : SHARE == 2 ? (u / 3) & 3 : 0;
+      acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ai]), __builtin_bit_cast(bf16x8, b[bi]), acc[u % CHAINS], 0, 0, 0);
 #pragma unroll
       for (int q = 0; q < VALU; ++q) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f[(u * VALU + q) & 7]) : "v"(fc));
     }
@@ -149,7 +159,7 @@ int main(int argc, char** argv) {
   float* sink;
   unsigned long long* cyc;
   if (hipMalloc(&sink, size_t(cus) * threads * 4) != hipSuccess || hipMalloc(&cyc, size_t(cus) * threads / 64 * 8) != hipSuccess) return 1;
-  const int dma = argc > 7 ? atoi(argv[7]) : 0, hbm = argc > 8 ? atoi(argv[8]) : 0;
+  const int dma = argc > 7 ? atoi(argv[7]) : 0, hbm = argc > 8 ? atoi(argv[8]) : 0, share = argc > 9 ? atoi(argv[9]) : 0;
   u32x4 *wstream = nullptr, *hbm_in = nullptr, *hbm_out = nullptr;
   if (dma) {
     if (hipMalloc(&wstream, 4u << 20) != hipSuccess) return 1;
@@ -167,7 +177,9 @@ int main(int argc, char** argv) {
     (void)hipMemset(hbm_in, 0x3c, size_t(1) << 30);
   }
   void (*kern)(float*, unsigned long long*, int, int, const u32x4*, const u32x4*, u32x4*) = nullptr;
-  if (dma || hbm) {
+  if (share) {
+    if (chains == 2 && !ldsr && !valu && !dma && !hbm) kern = share == 1 ? k<2, 0, 0, 0, 0, 1> : share == 2 ? k<2, 0, 0, 0, 0, 2> : k<2, 0, 0, 0, 0, 3>;
+  } else if (dma || hbm) {
     if (chains == 2 && ldsr == 1 && valu == 3 && dma == 1 && hbm == 0) kern = k<2, 1, 3, 1, 0>;
     else if (chains == 2 && ldsr == 1 && valu == 3 && dma == 1 && hbm == 1) kern = k<2, 1, 3, 1, 1>;
     else if (chains == 2 && ldsr == 1 && valu == 3 && dma == 0 && hbm == 1) kern = k<2, 1, 3, 0, 1>;
@@ -215,8 +227,8 @@ int main(int argc, char** argv) {
   const double mfma_per_wave_s = n_mfma / (cus * 4.0 * wps) / (ms * 1e-3);
   const double dma_tbs = dma ? mfma_per_wave_s / 8.0 * 1024.0 * cus * 4.0 * wps / 1e12 : 0.0;
   const double hbm_tbs = hbm ? mfma_per_wave_s / 128.0 * (1024.0 + 1024.0 * 1.25) * cus * 4.0 * wps / 1e12 : 0.0;
-  printf("{\"waves_per_simd\": %d, \"chains\": %d, \"pattern\": %d, \"lds_reads_per_2_mfma\": %d, \"valu_per_mfma\": %d, \"lds_dma_weight_stream\": %d, \"hbm_streams\": %d, \"cus\": %d, \"seconds\": %.3f, \"tflops_bf16\": %.1f, \"frac_of_2500\": %.4f, "
+  printf("{\"waves_per_simd\": %d, \"chains\": %d, \"pattern\": %d, \"lds_reads_per_2_mfma\": %d, \"valu_per_mfma\": %d, \"lds_dma_weight_stream\": %d, \"hbm_streams\": %d, \"operand_sharing\": %d, \"cus\": %d, \"seconds\": %.3f, \"tflops_bf16\": %.1f, \"frac_of_2500\": %.4f, "
          "\"mfma_per_simd_per_s\": %.4e, \"l2_to_lds_tb_per_s\": %.2f, \"hbm_tb_per_s\": %.2f}\n",
-         wps, chains, pattern, ldsr, valu, dma, hbm, cus, ms * 1e-3, tflops, tflops / 2500.0, n_mfma / (cus * 4.0) / (ms * 1e-3), dma_tbs, hbm_tbs);
+         wps, chains, pattern, ldsr, valu, dma, hbm, share, cus, ms * 1e-3, tflops, tflops / 2500.0, n_mfma / (cus * 4.0) / (ms * 1e-3), dma_tbs, hbm_tbs);
   return 0;
 }
