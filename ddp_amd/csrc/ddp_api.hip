@@ -102,6 +102,7 @@ struct Layout {
   float* ubuf;                                          // u = W_m . m_t, fp32 fragment-major (fused seg tails)
   float* tlut;                                          // (Kc + 1, 256) = W_m . LUT^T
   unsigned char* tail4_stream;                          // fused tail: conv_seg images + layer 0's 11 projection images
+  unsigned char* head7_stream;                          // first step's head from NCHW (k_layer MODE 7): W_m 8 wide + W_x 8 wide + 11
   unsigned char* lt_stream;                             // last layer + tail (k_layer MODE 6): 72 stages of layer L-1 + tail4_stream
   float* lt_bias;                                       //   fc1 bias of layer L-1 | layer 0's value_proj bias at [1024, 1280)
   float* tail4_bias;                                    //             conv_seg bias | layer 0's value_proj bias at [1024, 1280)
@@ -153,7 +154,7 @@ int validate(const ddp_cfg* c) {
     return DDP_E_BADCFG;
   }
   if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO |
-                   DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL)) {
+                   DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL | DDP_FLAG_SB_HEAD)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -243,6 +244,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->pro_bias = cv.take(size_t(b3_layer_bias_floats()));
     o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
     o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
+    o->head7_stream = (segp && o->Cx == 256) ? reinterpret_cast<unsigned char*>(cv.take(size_t(8 + 8 + 11) * 48 * 1024 / sizeof(float))) : nullptr;
     const bool lt = segp && o->L >= 1 && b3_layer_tail_supported(o->Kc);
     o->lt_stream = lt ? reinterpret_cast<unsigned char*>(cv.take(size_t(72 + 8 + 11) * 48 * 1024 / sizeof(float))) : nullptr;
     o->lt_bias = lt ? cv.take(size_t(b3_layer_bias_floats())) : nullptr;
@@ -254,6 +256,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->pro_bias = nullptr;
     o->tail4_stream = nullptr;
     o->tail4_bias = nullptr;
+    o->head7_stream = nullptr;
     o->lt_stream = nullptr;
     o->lt_bias = nullptr;
     o->tlut = nullptr;
@@ -471,6 +474,15 @@ int prepare_model(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipSt
           hipMemcpyAsync(o.pro_bias + DDP_FFN, w->layers[0].value_proj_b, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) !=
               hipSuccess) {
         set_error("prologue bias copy failed");
+        return DDP_E_LAUNCH;
+      }
+    }
+    if (o.head7_stream) {               // first step's head from NCHW (k_layer MODE 7): [W_m: 8 wide][W_x: 8 wide][layer 0's Wv, Wcat as above]
+      DDP_TRY(launch_build_stages(o.wp_m.p, o.wp_m.comp_stride, 256, 256, 0, 1, 8, 0, 2, 1, 0, o.head7_stream, st));
+      DDP_TRY(launch_build_stages(o.wp_x.p, o.wp_x.comp_stride, 256, 256, 0, 1, 8, 8, 2, 1, 0, o.head7_stream, st));
+      if (hipMemcpyAsync(o.head7_stream + size_t(16) * 48 * 1024, o.pro_stream + size_t(8) * 48 * 1024, size_t(11) * 48 * 1024,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("first-step head stream copy failed");
         return DDP_E_LAUNCH;
       }
     }
@@ -767,8 +779,15 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   const int M = int(o.M), M0 = int(o.M0);
   const BevGeom geom = bev_geom(cfg);
 
+  // seg + DDIM u chain with one noisy map per image: the first step's head reads the caller's NCHW x and start noise directly
+  // (k_layer MODE 7) and writes xproj itself - no NCHW -> SB conversions, no x-projection GEMM
+  const bool head7 = o.b3 && o.fused_layer && o.fused_pro && cfg->task == DDP_TASK_SEG && cfg->sampler == DDP_SAMPLER_DDIM &&
+                     o.h == o.hh && o.w == o.wh && o.r == 1 && o.head7_stream && !(cfg->flags & DDP_FLAG_SB_HEAD) &&
+                     !((size_t(o.M) * 256) >> 32);
   // loop-invariant half of the concat-conv: xproj = W_x x + b  (ddp.py:223-224 with the x columns hoisted)
-  if (o.b3) {
+  if (head7) {
+    // (inside the first step's head)
+  } else if (o.b3) {
     DDP_TRY(launch_nchw_to_sb(d_x, o.in_sb, o.B, o.Cx, o.N, st));       // NCHW -> split fragments in one pass
     DDP_TRY(launch_b3_linear(o.in_sb, o.wp_x, weights->transform_b, nullptr, 0, 0, 0, o.xproj, 256, o.B * o.N, 256, o.Cx, st,
                              TAG_XPROJ));
@@ -786,6 +805,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       set_error("noise copy failed");
       return DDP_E_LAUNCH;
     }
+  } else if (head7) {
+    // (the first step's head reads d_noise itself)
   } else if (seg_tail) {
     DDP_TRY(launch_nchw_to_sb(d_noise, o.in_sb, o.R, 256, o.N, st));    // the noisy map only ever exists as SB on this path
   } else {
@@ -859,7 +880,13 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         pl.px = o.px[0];
         pl.n_tok = o.Nh;
         pl.w = o.wh;
-        DDP_TRY(launch_b3_prologue(pl, st));
+        if (head7) {
+          pl.mask_sb = nullptr;
+          pl.stream = o.head7_stream;
+          DDP_TRY(launch_b3_head_nchw(pl, d_noise, d_x, weights->transform_b, st));
+        } else {
+          DDP_TRY(launch_b3_prologue(pl, st));
+        }
       } else if (o.b3) {
         // separate concat-conv GEMM: SB for the tile-GEMM layers, and fp32 fragments for the layer kernels
         DDP_TRY(launch_b3_linear_sb(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.q_sb, o.fused_layer ? o.q : nullptr, M0,

@@ -164,6 +164,11 @@ struct PrologueLaunch {
   int n_tok, w;
 };
 int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
+// the head of the FIRST step straight from the caller's NCHW tensors (k_layer MODE 7, ddp_layer_tail.hip): u_0 = W_m . noise,
+// xproj = W_x x + b (written as fp32 rows: the loop-invariant half of the concat-conv), q = xproj + u_0, layer 0's projections.
+// One noisy map per image, 256 feature channels.  `a.mask_sb` unused, `a.res` = xproj OUT, stream = 8 wide stages of W_m + 8 of
+// W_x + the 11 projection images.
+int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const float* nchw_x, const float* bias, hipStream_t st);
 // layer 0's value / sampling projections alone (k_layer MODE 3): q given as SB (res == nullptr), or formed as the depth
 // concat-conv q = res[row] + wm * dvec[m] and written to Q.  stream = the 11 projection images, bias_ext as PrologueLaunch.
 struct L0ProjLaunch {

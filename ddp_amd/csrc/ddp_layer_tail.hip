@@ -100,4 +100,44 @@ int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsign
   return (t.num_classes + 63) / 64 == 1 ? launch_lt_n<1>(la, grid, st) : launch_lt_n<3>(la, grid, st);
 }
 
+int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const float* nchw_x, const float* bias, hipStream_t st) {
+  if (a.M <= 0) return DDP_OK;
+  if (a.res_rn != 0 || !a.res || (size_t(a.M) * 256) >> 32) {
+    set_error("first-step head from NCHW: one noisy map per image and < 2^32 elements per tensor");
+    return DDP_E_BADCFG;
+  }
+  b3::LayerArgs la;
+  memset(&la, 0, sizeof(la));
+  la.nchw_noise = nchw_noise;
+  la.nchw_x = nchw_x;
+  la.bo = bias;
+  la.Q = a.Q;
+  la.stream = a.stream;
+  la.bias_ext = a.bias_ext;
+  la.res = a.res;
+  la.ubuf = a.ubuf;
+  la.M = a.M;
+  la.has_next = 1;
+  la.v_out = a.v_out;
+  la.samp_out = a.samp_out;
+  la.py = a.py;
+  la.px = a.px;
+  la.n_tok = a.n_tok;
+  la.w = a.w;
+  const int n_cu = cu_count();
+  const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  static LdsAttrOnce attr, attr_nt;
+  prof_begin(TAG_FEAT, st);
+  if (a.M >= b3::LYR_NT_MIN_TOKENS) {
+    attr_nt.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FEAT, 7, 0, true>), int(b3::LYR_LDS_B));
+    hipLaunchKernelGGL((b3::k_layer<TAG_FEAT, 7, 0, true>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  } else {
+    attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FEAT, 7>), int(b3::LYR_LDS_B));
+    hipLaunchKernelGGL((b3::k_layer<TAG_FEAT, 7>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  }
+  prof_end(TAG_FEAT, st);
+  return check_launch("b3::k_layer (first step's head from NCHW)");
+}
+
 }  // namespace ddp

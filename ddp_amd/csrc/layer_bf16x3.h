@@ -38,6 +38,11 @@
 //   3  layer 0's projections alone (bev, ddp_head_forward) / the depth step head (one-channel concat-conv, no GEMM);
 //   4  tail of step s fused with the head of step s + 1: the DDIM update runs on u = W_m . m (affine in u and a row of
 //      the table W_m . LUT) - no concat-conv GEMM and no 256-channel noisy map after step 0.
+//   7  the head of the FIRST step straight from the caller's NCHW tensors: u_0 = W_m . noise (8 wide stages), xproj = W_x x + b
+//      (8 more), q = xproj + u_0, layer 0's projections.  The B fragments are read from the NCHW planes with 16 coalesced dword
+//      loads per stage (a lane's token is a column of the MFMA, 32 x-adjacent tokens = one 128-B run of a channel plane) and
+//      split in the filler slots like the attention output of MODE 0: replaces two NCHW -> SB conversions, the x-projection
+//      GEMM and MODE 2 (ddp.py:223-224 with the x columns hoisted out of the loop).
 //   6  the LAST decoder layer of a step (MODE 0 without a next layer) + that step's tail (MODE 4, or MODE 1 after the last
 //      step: has_next = 0) in one kernel: LayerNorm1's split output IS conv_seg's operand, exactly as it feeds P3 in MODE 0,
 //      so the layer output never travels to HBM (1 KiB written + 1 KiB read per token and step) and a launch with its
@@ -115,6 +120,10 @@ struct LayerArgs {
   // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
   // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
   const float* dvec;             // (M) noisy depth map
+  // MODE 7 (first step's head from NCHW): S = nullptr; noise / x planes (maps of n_tok tokens, 256 channels each; one noisy map
+  // per image), `bo` = the concat-conv's bias, res = xproj OUT (fp32 rows of 256), ubuf = u_0 out
+  const float* nchw_noise;
+  const float* nchw_x;
   // MODE 6 (last layer + seg tail): conv_seg's bias, zero padded to 256 floats (bias_ext holds fc1's bias and, at [1024, 1280),
   // layer 0's value_proj bias); has_next = "a next STEP follows" (MODE 4's part: u update, next q, layer 0's projections)
   const float* seg_bias;
@@ -388,6 +397,7 @@ k_layer(LayerArgs la) {
   int n_stages = MODE == 5 ? la.gp[gp_of(int(blockIdx.x))].ns
                        : MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
                        : MODE == 6 ? LYR_ST_OUT + LYR_ST_FFN + 2 * NCH + (la.has_next ? LYR_ST_NEXT : 0)
+                       : MODE == 7 ? 2 * LYR_ST_OUT + LYR_ST_NEXT
                                                                                     : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
   unsigned long long nb = 0;                                   // its base (+ this wave's share), set by stage_begin
@@ -531,6 +541,7 @@ k_layer(LayerArgs la) {
     if constexpr (MODE != 5)
       for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
     if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
+    if constexpr (MODE == 7) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // the concat-conv's bias
     if constexpr (MODE == 6) tab[LYR_T_SEG + tid] = la.seg_bias[tid];
     if constexpr (MODE == 0 || MODE == 6) {
       tab[LYR_T_BO + tid] = la.bo[tid];
@@ -900,17 +911,43 @@ k_layer(LayerArgs la) {
         load_q_fragments(qf);
       }
     }
-    if constexpr (MODE == 0 || MODE == 2 || MODE == 6) {
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 6 || MODE == 7) {
     {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
     // MODE 0: the attention output arrives as fp32 fragments (la.Sf): per stage (32 channels = tile t) four quads
-    constexpr bool SF = (MODE == 0 || MODE == 6) && (DDP_S_F32 != 0);
+    constexpr bool SF = ((MODE == 0 || MODE == 6) && (DDP_S_F32 != 0)) || MODE == 7;
     f32x4 sf[4], sh[2];
     const float* sfp = la.Sf + grp * 8192 + lane * 4;
-    if constexpr (SF) {
+    // MODE 7: this lane's token in the NCHW planes: element offset of (map, channel 4h, token n); stage st (0..7 noise, 8..15 x)
+    // reads channels 32 (st & 7) + 8g + 4h + e - 16 dword loads, each a 128-B run per half wave
+    unsigned nchw_off = 0;
+    if constexpr (MODE == 7) {
+      int ntk7 = la.n_tok;
+      asm volatile("" : "+s"(ntk7));                           // (opaque per tile: see P3's index arithmetic)
+      int m7 = m_base + j;
+      m7 = m7 < M ? m7 : M - 1;
+      const int img7 = m7 / ntk7;
+      nchw_off = unsigned((img7 * 256 + 4 * h) * ntk7 + (m7 - img7 * ntk7));
+    }
+    auto sf_fetch = [&](int stn) __attribute__((always_inline)) {          // the fp32 operand fragments of stage stn -> sf[0..3]
+      if constexpr (MODE == 7) {
+        const float* plane = (stn < 8 ? la.nchw_noise : la.nchw_x) + size_t(32 * (stn & 7)) * la.n_tok;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + g * 256);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* cb = plane + size_t(8 * g + e) * la.n_tok;              // uniform: the channel plane (+ 4h in nchw_off)
+            if constexpr (NT) sf[g][e] = __builtin_nontemporal_load(cb + nchw_off);
+            else sf[g][e] = cb[nchw_off];
+          }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + stn * 1024 + g * 256);
+      }
+    };
+    if constexpr (SF) {
+      sf_fetch(0);
     } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -954,8 +991,7 @@ k_layer(LayerArgs la) {
       if constexpr (!last) {
         const int stn = st + 1;
         if constexpr (SF) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + stn * 1024 + g * 256);
+          sf_fetch(stn);
         } else {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
@@ -1020,6 +1056,58 @@ k_layer(LayerArgs la) {
     DDP_LYR_STAMP_AT(11)                                       // stage 0 (waits for the tile's first fragments)
     for (int st = 1; st < 6; ++st) p0_stage(st, I0, I0);
     DDP_LYR_STAMP_AT(12)                                       // stages 1..5
+    if constexpr (MODE == 7) {
+      // stages 6, 7 finish u_0 = W_m . noise; its accumulators are copied aside (and stored for the u recursion of the following
+      // steps), the SAME accumulators restart from the concat-conv's bias and take the eight W_x stages: xproj.  (Continuing the
+      // accumulation instead would give q but not u_0 - the roundings of "0 + products" and "xproj + products" differ.)
+      p0_stage(6, I0, I0);
+      p0_stage(7, I0, I0);
+      f32x16 accu[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) accu[t] = acc2[t];
+      if (la.ubuf) {
+        float* ub = la.ubuf + grp * 8192 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(ub + t * 1024 + g * 256) = f32x4{acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
+        }
+      for (int st = 8; st < 15; ++st) p0_stage(st, I0, I0);
+      p0_stage(15, I1, I0);
+      // xproj rows out (the loop-invariant half of the concat-conv: every later step's tail reads them), q = xproj + u_0
+      {
+        const int m = m_base + j;
+        if (m < M) {
+          float* rp = const_cast<float*>(la.res) + size_t(m) * 256 + 4 * h;
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<f32x4*>(rp + t * 32 + 8 * g) = f32x4{acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int b = 2 * t + gp;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = accu[t][8 * gp + e] + acc2[t][8 * gp + e];
+          split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
+          store_q_block(qf, b, xv);
+        }
+      }
+    }
     if constexpr (MODE == 2) {
       // residual rows (fp32, W_x x + b): fetched under the last two stages, then q = acc2 + res -> SB + fragments
       f32x4 xr[8][4];
@@ -1490,7 +1578,7 @@ k_layer(LayerArgs la) {
     if constexpr (MODE != 1) {
     refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
-    if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || la.has_next) {       // (MODE 6 without a next step left the tile above)
+    if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || la.has_next) {       // (MODE 6 without a next step left the tile above)
       const int m = m_base + j;
       const bool valid = m < M;
       const int mm = valid ? m : M - 1;

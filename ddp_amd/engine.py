@@ -110,7 +110,7 @@ class DDPEngine:
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
                  weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False,
-                 gather_guess_zero=False, force_x0=False, fused_tail=None):
+                 gather_guess_zero=False, force_x0=False, fused_tail=None, nchw_head=None):
         self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -149,8 +149,10 @@ class DDPEngine:
             fused_prologue = os.environ.get('DDP_PROLOGUE_FUSED', '1') != '0'
         if fused_tail is None:     # DDP_TAIL_FUSED=0: the last layer of a step and the seg tail as two kernels (A/B runs, tests)
             fused_tail = os.environ.get('DDP_TAIL_FUSED', '1') != '0'
+        if nchw_head is None:      # DDP_NCHW_HEAD=0: the first step's head through the SB conversions + x-projection GEMM + MODE 2
+            nchw_head = os.environ.get('DDP_NCHW_HEAD', '1') != '0'
         cfg.flags = ((0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE) |
-                     (0 if fused_tail else _lib.FLAG_UNFUSED_TAIL))
+                     (0 if fused_tail else _lib.FLAG_UNFUSED_TAIL) | (0 if nchw_head else _lib.FLAG_SB_HEAD))
         if record_x0:
             cfg.flags |= _lib.FLAG_RECORD_X0
         if force_x0:               # test instrument (seg): teacher forcing, see set_x0_decisions()

@@ -242,6 +242,8 @@ VARIANTS = {'bf16x3': dict(gemm='bf16x3'), 'f32': dict(gemm='f32'),
             'bf16x3-unfused-prologue': dict(gemm='bf16x3', fused_prologue=False),
             # the last layer of a step and the seg tail as the two kernels they were fused from (DDP_FLAG_UNFUSED_TAIL)
             'bf16x3-unfused-tail': dict(gemm='bf16x3', fused_tail=False),
+            # the first step's head as NCHW -> SB conversions + x-projection GEMM + k_layer MODE 2 (DDP_FLAG_SB_HEAD)
+            'bf16x3-sb-head': dict(gemm='bf16x3', nchw_head=False),
             # the LDS gather's "actual mean offset is far from the guess: refill the window" branch (DDP_FLAG_GATHER_GUESS_ZERO)
             'bf16x3-gather-refill': dict(gemm='bf16x3', gather_guess_zero=True)}
 

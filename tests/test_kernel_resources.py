@@ -52,7 +52,7 @@ def test_layer_tail_kernels_have_no_scratch(tmp_path):
         body = m.group(2)
         assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0, m.group(1)
         assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 512
-    assert found == 6          # {1..64, 129..192 classes} x {plain, non-temporal, teacher-forced}
+    assert found == 8          # MODE 6: {1..64, 129..192 classes} x {plain, non-temporal, teacher-forced}; MODE 7: {plain, non-temporal}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
