@@ -358,6 +358,9 @@ constexpr int LYR_NSTAMP = 16;
 // the two kernels, the hint throws that away (gather 0.0208 -> 0.0252 ms, -3 % on the image) - hence a template parameter
 // chosen per launch by the token count (launch_b3_layer), not a build switch.  (The same hint on the GATHER's own table loads
 // and result stores costs it 1 %: not used.)
+// (round 5, same-box A/B profiles/r05g_ab_samp_hint_m7_pointer.txt: the sample table's stores WITHOUT the hint while v' keeps it -
+// could the 100 MB table stay in the 256 MB memory-side cache until the gather's first loads ask for it? - changes nothing: gather
+// 0.1538 vs 0.1535 ms)
 constexpr int LYR_NT_MIN_TOKENS = 131072;                    // >= 128 MiB per fp32 activation tensor: beyond L2 + MALL reuse
 template <bool NT>
 __device__ __forceinline__ f32x4 ld_stream(const float* p) {
@@ -933,14 +936,21 @@ k_layer(LayerArgs la) {
     auto sf_fetch = [&](int stn) __attribute__((always_inline)) {          // the fp32 operand fragments of stage stn -> sf[0..3]
       if constexpr (MODE == 7) {
         const float* plane = (stn < 8 ? la.nchw_noise : la.nchw_x) + size_t(32 * (stn & 7)) * la.n_tok;
+        // ONE per-lane pointer walking the 16 channel planes (strides N, N, N, 5 N: channels 8g + e, the lane's half adds 4):
+        // with 16 independent uniform plane addresses the compiler keeps 32 SGPRs of offsets alive across the kernel and spills
+        // them to VGPR lanes (32 v_readlane in front of every stage's loads; no measurable difference in time, 173 fewer lane moves)
+        const float* p = plane + nchw_off;
+        const size_t nstr = size_t(la.n_tok);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float* cb = plane + size_t(8 * g + e) * la.n_tok;              // uniform: the channel plane (+ 4h in nchw_off)
-            if constexpr (NT) sf[g][e] = __builtin_nontemporal_load(cb + nchw_off);
-            else sf[g][e] = cb[nchw_off];
+            asm volatile("" : "+v"(p));
+            if constexpr (NT) sf[g][e] = __builtin_nontemporal_load(p);
+            else sf[g][e] = *p;
+            p += e == 3 ? 5 * nstr : nstr;
           }
+        }
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) sf[g] = ld_stream<NT>(sfp + stn * 1024 + g * 256);
