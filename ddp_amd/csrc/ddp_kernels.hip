@@ -1177,7 +1177,7 @@ __global__ void __launch_bounds__(256) k_depth_aug_postprocess(DepthAugArgs a) {
     for (int q = 0; q < 4; ++q) acc[q] = acc[q] / nf;
   }
   float* o = a.out + (size_t(b) * a.oh + y) * a.ow + x0;
-  if ((a.ow & 3) == 0) {
+  if ((a.ow & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0) {       // (a caller's view may start at any float)
     *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   } else {
 #pragma unroll

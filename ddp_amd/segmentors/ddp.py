@@ -291,6 +291,8 @@ class DDP(nn.Module, _SamplerMixin):
         materialises per augmentation and the running sum at ori_shape never exist."""
         from ..engine import seg_aug_postprocess
         assert rescale, 'aug_test rescales every augmentation back to ori_shape'
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
         if self._mode() == 'slide':
             # no shipped config combines sliding windows with test-time augmentation: the reference's own composition
             # (running mean of ``inference``, encoder_decoder.py:306-331) over the fused per-augmentation slide epilogue
@@ -299,8 +301,6 @@ class DDP(nn.Module, _SamplerMixin):
                 prob += self.inference(img, meta, rescale)
             prob /= len(imgs)
             return list(prob.argmax(dim=1).cpu().numpy().astype('int64'))
-        if len(imgs) != len(img_metas):
-            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
         ori_shape = tuple(img_metas[0][0]['ori_shape'][:2])
         scores, metas = [], []
         for img, meta in zip(imgs, img_metas):
@@ -338,6 +338,10 @@ class DDP(nn.Module, _SamplerMixin):
             if img_meta and any(self._epilogue_args(m, rescale) != self._epilogue_args(img_meta[0], rescale) for m in img_meta):
                 raise ValueError('slide inference: the images of a batch must share img_shape / ori_shape / flip')
             fl = self._epilogue_args(img_meta[0], rescale)[2] if img_meta else None
+            # ('seg' = argmax of the window-averaged SCORES; the reference takes argmax of their softmax, encoder_decoder.py:277,296.
+            # softmax is monotone, so the two agree except where fp32 rounding of exp / the division makes two probabilities EQUAL
+            # that came from different scores - the reference then returns the lower class index, this path the class with the
+            # larger score.  test_slide_epilogue_golden bounds it: identical wherever the reference's top-2 margin exceeds 1e-5.)
             return list(self._slide(img, img_meta, rescale, 'seg', fl).cpu().numpy().astype('int64'))
         x = self.extract_feat(img)[0]
         if self.diffusion == 'ddim':
