@@ -16,6 +16,7 @@ TASK_SEG, TASK_DEPTH, TASK_BEV = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1
 FLAG_UNFUSED_LAYER, FLAG_UNFUSED_PROLOGUE, FLAG_RECORD_X0, FLAG_GATHER_GUESS_ZERO, FLAG_FCN_PREPARED, FLAG_FORCE_X0, FLAG_UNFUSED_TAIL, FLAG_SB_HEAD = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_DEPTH_SCALE_UP, FLAG_DEPTH_NO_EPS = 256, 512
 NECK_WEIGHTS_READY = 1
 
 _fp = C.c_void_p  # device pointers travel as raw addresses

@@ -154,7 +154,7 @@ int validate(const ddp_cfg* c) {
     return DDP_E_BADCFG;
   }
   if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO |
-                   DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL | DDP_FLAG_SB_HEAD)) {
+                   DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL | DDP_FLAG_SB_HEAD | DDP_FLAG_DEPTH_SCALE_UP | DDP_FLAG_DEPTH_NO_EPS)) {
     set_error("unknown flags 0x%x", c->flags);
     return DDP_E_BADCFG;
   }
@@ -984,7 +984,8 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       a.min_depth = cfg->min_depth;
       a.max_depth = cfg->max_depth;
       a.bit_scale = cfg->bit_scale;
-      a.eps_depth = cfg->min_depth;
+      a.scale_up = (cfg->flags & DDP_FLAG_DEPTH_SCALE_UP) ? 1 : 0;      // decode_head.py:252-262
+      a.eps_depth = (cfg->flags & DDP_FLAG_DEPTH_NO_EPS) ? (a.scale_up ? 1.0f : 0.0f) : (a.scale_up ? cfg->max_depth : cfg->min_depth);
       a.st = sp;
       DDP_TRY(launch_depth_update(a, st));
     } else {
@@ -1088,7 +1089,8 @@ int ddp_head_forward(const ddp_cfg* cfg, const ddp_weights* weights, const float
     a.min_depth = cfg->min_depth;
     a.max_depth = cfg->max_depth;
     a.bit_scale = cfg->bit_scale;
-    a.eps_depth = cfg->min_depth;
+    a.scale_up = (cfg->flags & DDP_FLAG_DEPTH_SCALE_UP) ? 1 : 0;      // decode_head.py:252-262
+      a.eps_depth = (cfg->flags & DDP_FLAG_DEPTH_NO_EPS) ? (a.scale_up ? 1.0f : 0.0f) : (a.scale_up ? cfg->max_depth : cfg->min_depth);
     DDP_TRY(launch_depth_update(a, st));
   } else {
     if (o.b3)
@@ -1379,7 +1381,7 @@ int ddp_seg_slide_postprocess(const float* const* d_scores, const int* win_y1, c
               prob_mode);
     return DDP_E_BADCFG;
   }
-  // every image pixel covered, by at most 3 window rows / columns (the kernel keeps that many per tap in registers)
+  // every image pixel covered, by at most 4 window rows / columns (the kernel keeps that many per tap in registers)
   for (int axis = 0; axis < 2; ++axis) {
     const int* o = axis ? win_x1 : win_y1;
     const int n = axis ? n_cols : n_rows, crop = axis ? crop_w : crop_h, size = axis ? img_w : img_h;
@@ -1390,8 +1392,8 @@ int ddp_seg_slide_postprocess(const float* const* d_scores, const int* win_y1, c
         return DDP_E_BADCFG;
       }
       covered = o[i] + crop;
-      if (i >= 3 && o[i - 3] + crop > o[i]) {
-        set_error("seg_slide_postprocess: more than 3 windows overlap along axis %d (stride < crop / 3)", axis);
+      if (i >= 4 && o[i - 4] + crop > o[i]) {
+        set_error("seg_slide_postprocess: more than 4 windows overlap along axis %d (stride < crop / 4)", axis);
         return DDP_E_BADCFG;
       }
     }

@@ -302,6 +302,7 @@ struct DepthUpdateArgs {
   float* pred;         // (M) metric depth prediction out
   int B_r, h, w;
   float min_depth, max_depth, bit_scale, eps_depth;
+  int scale_up;             // depth = sigmoid(s) * eps_depth instead of relu(s) + eps_depth
   ddp_step st;
 };
 int launch_depth_update(const DepthUpdateArgs& a, hipStream_t st);

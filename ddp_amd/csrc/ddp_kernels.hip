@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_seg_aug_postprocess(SegAugArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Sliding-window inference epilogue (encoder_decoder.py:180-227 slide_inference + :266-296 inference / simple_test), fused: see
 // ddp_seg_slide_postprocess in the header.  One thread per output pixel.  Window coverage is separable (a grid of window rows
-// x columns), so per stage-2 tap the thread keeps the <= 3 covering rows and <= 3 covering columns with their stage-1
+// x columns), so per stage-2 tap the thread keeps the <= 4 covering rows and <= 4 covering columns with their stage-1
 // interpolation indices in registers and then walks the classes: value(tap, c) = sum over covering (row, col), row-major as
 // the reference adds them, of bilerp(window scores) / count.  LDS (prob output only): K x 64 floats, column = thread.
 // ------------------------------------------------------------------------------------------------
@@ -1055,17 +1055,20 @@ struct SlideArgs {
   unsigned char* seg;
   float* prob;
 };
+// (4, not 3: clamping the last window back into the image puts a fourth window over pixels that stride >= crop / 3 alone
+// would cover three times - crop 9, stride 3, H = 16 gives origins 0, 3, 6, 7 - and the reference accepts such grids)
+constexpr int SLIDE_MAX_COVER = 4;
 struct SlideCover {
   int n;
-  int idx[3];
-  UpIdx u[3];
+  int idx[SLIDE_MAX_COVER];
+  UpIdx u[SLIDE_MAX_COVER];
 };
 __device__ __forceinline__ SlideCover slide_cover(int p, const int* start, int n_win, int crop, int lowres, int align) {
   SlideCover c;
   c.n = 0;
 #pragma unroll 1
   for (int i = 0; i < n_win; ++i)
-    if (p >= start[i] && p < start[i] + crop && c.n < 3) {
+    if (p >= start[i] && p < start[i] + crop && c.n < SLIDE_MAX_COVER) {
       c.idx[c.n] = i;
       c.u[c.n] = up_index(p - start[i], lowres, crop, align);
       ++c.n;
@@ -1739,6 +1742,7 @@ __global__ void __launch_bounds__(256) k_feat_depth(const float* __restrict__ xp
 }
 
 // taps (M,32): column t = dy*3+dx holds w[:,dy,dx] . q[m]; depth[i][j] = relu(sum_t taps[(i+dy-1, j+dx-1)][t] + b) + eps
+// (scale_up: sigmoid(.) * eps; depth/depth/models/decode_heads/decode_head.py:252-262)
 __global__ void __launch_bounds__(256) k_depth_update(DepthUpdateArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = a.h * a.w;
@@ -1754,7 +1758,7 @@ __global__ void __launch_bounds__(256) k_depth_update(DepthUpdateArgs a) {
       if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) s += a.taps[(size_t(img) * N + ii * a.w + jj) * 32 + dy * 3 + dx];
     }
   s += a.bias_ptr[0];
-  const float pred = fmaxf(s, 0.f) + a.eps_depth;
+  const float pred = a.scale_up ? a.eps_depth / (1.0f + expf(-s)) : fmaxf(s, 0.f) + a.eps_depth;
   a.pred[m] = pred;
   if (!a.depth_t) return;   // head-only call: no sampler update
   float x0 = (pred - a.min_depth) / (a.max_depth - a.min_depth);

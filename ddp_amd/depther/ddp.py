@@ -20,9 +20,9 @@ class DepthDeformableHeadWithTime(_SegHead):
 
     def __init__(self, min_depth=1e-3, max_depth=None, scale_up=False, classify=False, use_eps=True, n_bins=None,
                  init_inputs=False, **kwargs):
-        if scale_up or classify or not use_eps:
-            raise ValueError('only the regression branch used by the DDP configs is implemented '
-                             '(scale_up=False, classify=False, use_eps=True; decode_head.py:264-269)')
+        if classify:
+            raise ValueError('the regression branches of depth_pred are implemented (relu + eps, and scale_up: sigmoid * eps; '
+                             'decode_head.py:252-262); classify=True (binned depth, :236-250) is not - no DDP config uses it')
         self.min_depth, self.max_depth = min_depth, max_depth
         self.scale_up, self.classify, self.use_eps = scale_up, classify, use_eps
         kwargs.setdefault('num_classes', 1)
@@ -32,7 +32,8 @@ class DepthDeformableHeadWithTime(_SegHead):
         self.conv_depth = nn.Conv2d(self.channels, 1, kernel_size=3, padding=1, stride=1)
 
     def _engine_kwargs(self):
-        return dict(min_depth=self.min_depth, max_depth=self.max_depth if self.max_depth is not None else 80.0)
+        return dict(min_depth=self.min_depth, max_depth=self.max_depth if self.max_depth is not None else 80.0,
+                    depth_scale_up=bool(self.scale_up), depth_use_eps=bool(self.use_eps))
 
 
 @DEPTHER.register_module(name='DepthDDP')
@@ -83,14 +84,22 @@ class DDP(nn.Module, _SamplerMixin):
         if noise is None:
             noise = torch.randn((b, self.randsteps, 1, h, w), device=x.device)
 
+        head = self.decode_head
+        su, ue = bool(getattr(head, 'scale_up', False)), bool(getattr(head, 'use_eps', True))
+        # the library takes ONE (min_depth, max_depth): the head's eps of depth_pred (decode_head.py:252-262) and the depther's x0
+        # normalisation (depther/ddp.py:239) read the same pair in every shipped config
+        hmin, hmax = getattr(head, 'min_depth', self.min_depth), getattr(head, 'max_depth', None)
+        if ue and ((not su and hmin != self.min_depth) or (su and hmax is not None and hmax != self.max_depth)):
+            raise ValueError(f'decode_head min / max depth ({hmin}, {hmax}) differ from the depther\'s ({self.min_depth}, {self.max_depth})')
+
         def factory():
             from ..engine import DDPEngine
             return DDPEngine(self.hot_path_state_dict(), 'depth', h=h, w=w, batch=b, randsteps=self.randsteps,
                              timesteps=self.timesteps, bit_scale=self.bit_scale, time_difference=self.time_difference,
-                             min_depth=self.min_depth, max_depth=self.max_depth, device=x.device)
+                             min_depth=self.min_depth, max_depth=self.max_depth, depth_scale_up=su, depth_use_eps=ue, device=x.device)
         # keyed without the geometry: a new (b, h, w) re-uses the engine through set_geometry (no weight repacking)
         eng = self._get_engine(('depth', str(x.device), self.timesteps, self.randsteps, self.bit_scale, self.time_difference,
-                                self.min_depth, self.max_depth), factory, geometry=(b, h, w))
+                                self.min_depth, self.max_depth, su, ue), factory, geometry=(b, h, w))
         return eng.sample(x.contiguous().float(), noise.contiguous().float())
 
     def _decode_head_forward_test(self, x, t, img_metas=None):

@@ -110,7 +110,8 @@ class DDPEngine:
                  sampler='ddim', accumulation=False, min_depth=1e-3, max_depth=80.0, threshold=0.5,
                  head_hw=None, bev_input_scope=None, bev_output_scope=None, device=None, head_prefix='decode_head.',
                  weights=None, gemm=None, fused_layer=None, fused_prologue=None, lib_path=None, record_x0=False,
-                 gather_guess_zero=False, force_x0=False, fused_tail=None, nchw_head=None):
+                 gather_guess_zero=False, force_x0=False, fused_tail=None, nchw_head=None, depth_scale_up=False,
+                 depth_use_eps=True):
         self.lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise _lib.DdpError('no HIP device visible: ddp_amd has no CPU path')
@@ -153,6 +154,8 @@ class DDPEngine:
             nchw_head = os.environ.get('DDP_NCHW_HEAD', '1') != '0'
         cfg.flags = ((0 if fused_layer else _lib.FLAG_UNFUSED_LAYER) | (0 if fused_prologue else _lib.FLAG_UNFUSED_PROLOGUE) |
                      (0 if fused_tail else _lib.FLAG_UNFUSED_TAIL) | (0 if nchw_head else _lib.FLAG_SB_HEAD))
+        if task == 'depth':        # head variants of depth_pred (decode_head.py:252-262)
+            cfg.flags |= (_lib.FLAG_DEPTH_SCALE_UP if depth_scale_up else 0) | (0 if depth_use_eps else _lib.FLAG_DEPTH_NO_EPS)
         if record_x0:
             cfg.flags |= _lib.FLAG_RECORD_X0
         if force_x0:               # test instrument (seg): teacher forcing, see set_x0_decisions()

@@ -73,6 +73,9 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
 enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8,
        DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */,
        DDP_FLAG_FORCE_X0 = 32,
+       /* depth head variants (depth/depth/models/decode_heads/decode_head.py:252-262; model configuration, not diagnostics): */
+       DDP_FLAG_DEPTH_SCALE_UP = 256 /* depth = sigmoid(conv_depth) * eps, eps = max_depth (or 1 with NO_EPS) instead of relu(conv_depth) + eps */,
+       DDP_FLAG_DEPTH_NO_EPS = 512 /* use_eps=False: eps = 0 (relu branch) / 1 (scale_up branch) instead of min_depth / max_depth */,
        DDP_FLAG_SB_HEAD = 128 /* the first step's head as the four launches it was fused from (NCHW -> split fragments of x and of
                                   the start noise, the x-projection GEMM, k_layer MODE 2) instead of ONE kernel that reads the
                                   caller's NCHW tensors directly (k_layer MODE 7); A/B runs and parity tests of the separate kernels */,

@@ -241,15 +241,17 @@ def head_forward_seg(feat, temb, sd, core='gridsample', trace=None):
     return F.conv2d(mem, sd['decode_head.conv_seg.weight'], sd['decode_head.conv_seg.bias'])
 
 
-def head_forward_depth(feat, temb, sd, min_depth=1e-3, core='gridsample', trace=None):
+def head_forward_depth(feat, temb, sd, min_depth=1e-3, core='gridsample', trace=None, scale_up=False, use_eps=True, max_depth=80.0):
     """depth/depth/models/decode_heads/deformable_head_with_time.py:90-131 +
-    depth/depth/models/decode_heads/decode_head.py:100,264-269 (scale_up=False, use_eps=True):
-    relu(conv3x3(memory)) + min_depth."""
+    depth/depth/models/decode_heads/decode_head.py:100,252-262: relu(conv3x3(memory)) + eps (eps = min_depth, or 0 with
+    use_eps=False), or with scale_up sigmoid(conv3x3(memory)) * eps (eps = max_depth, or 1)."""
     bs, c, h, w = feat.shape
     mem = encoder_forward(feat, temb, sd, core, trace)
     mem = mem.permute(0, 2, 1).reshape(bs, c, h, w).contiguous()
     d = F.conv2d(mem, sd['decode_head.conv_depth.weight'], sd['decode_head.conv_depth.bias'], padding=1)
-    return F.relu(d) + min_depth
+    if scale_up:
+        return torch.sigmoid(d) * (max_depth if use_eps else 1)
+    return F.relu(d) + (min_depth if use_eps else 0)
 
 
 # --------------------------------------------------------------------------------------------
@@ -401,7 +403,7 @@ def fcn_head_for_sampler(sd, num_convs, dilation=1, prefix='decode_head.'):
 
 
 def sample_depth(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.1, time_difference=1,
-                 min_depth=1e-3, max_depth=80.0, core='gridsample', trace=None):
+                 min_depth=1e-3, max_depth=80.0, core='gridsample', trace=None, scale_up=False, use_eps=True):
     """depth/depth/models/depther/ddp.py:229-247 (+ ddim_step :220-227) for ONE image.
     x (1,256,h,w); noise (r,1,h,w).  -> (1,1,h,w) metric depth (before the encode_decode clamp)."""
     xr = x.repeat(randsteps, 1, 1, 1)
@@ -412,7 +414,7 @@ def sample_depth(x, noise, sd, timesteps=3, randsteps=1, bit_scale=0.1, time_dif
         times_next = torch.tensor([t_next], dtype=torch.float32)
         feat = F.conv2d(torch.cat([xr, depth_t], dim=1), sd['down.conv.weight'], sd['down.conv.bias'])
         temb = time_mlp(times_now, sd)                                   # raw t, not log-snr (:238)
-        depth_pred = head_forward_depth(feat, temb, sd, min_depth, core)
+        depth_pred = head_forward_depth(feat, temb, sd, min_depth, core, None, scale_up, use_eps, max_depth)
         x0 = (depth_pred - min_depth) / (max_depth - min_depth)
         x0 = (x0 * 2 - 1) * bit_scale
         a_now = gamma_cosine(times_now.view(-1, 1, 1, 1))

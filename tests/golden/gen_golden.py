@@ -68,6 +68,11 @@ DEPTH_CASES = [
          min_depth=1e-3, max_depth=80.0),
     dict(name='depth_td2', h=7, w=13, timesteps=4, randsteps=1, bit_scale=0.1, seed=12,
          min_depth=1e-3, max_depth=80.0, time_difference=2),
+    # the other regression branches of depth_pred (depth/depth/models/decode_heads/decode_head.py:252-262): sigmoid * max_depth, eps = 0
+    dict(name='depth_scale_up', h=9, w=10, timesteps=3, randsteps=1, bit_scale=0.1, seed=13,
+         min_depth=1e-3, max_depth=10.0, scale_up=True),
+    dict(name='depth_no_eps', h=6, w=15, timesteps=3, randsteps=2, bit_scale=0.1, seed=14,
+         min_depth=1e-3, max_depth=80.0, use_eps=False),
 ]
 
 BEV_CASES = [
@@ -227,6 +232,11 @@ def gen_depth():
         m.max_depth = case['max_depth']
         if 'time_difference' in case:
             m.time_difference = case['time_difference']
+        m.decode_head.min_depth, m.decode_head.max_depth = case['min_depth'], case['max_depth']
+        if 'scale_up' in case:
+            m.decode_head.scale_up = case['scale_up']
+        if 'use_eps' in case:
+            m.decode_head.use_eps = case['use_eps']
         model = revert_sync_batchnorm(build_depther(m)).eval()
         assert hasattr(model.decode_head.encoder.layers[0], 'time_mlp'), 'time-aware layer not registered'
         sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=case['seed'] + 100)

@@ -34,7 +34,8 @@ def _engine(cfg, sd, dev, batch=1, **over):
                   noise_schedule=cfg['noise_schedule'], sampler=cfg['diffusion'],
                   sample_range0=cfg.get('sample_range', (0.0, 0.999))[0])
     elif task == 'depth':
-        kw.update(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'])
+        kw.update(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'], depth_scale_up=cfg.get('scale_up', False),
+                  depth_use_eps=cfg.get('use_eps', True))
     else:
         kw.update(num_classes=6, feat_channels=cfg['feat_channels'], bev_input_scope=cfg['input_scope'],
                   bev_output_scope=cfg['output_scope'])
@@ -414,8 +415,15 @@ def test_slide_epilogue_cityscapes_size_and_errors():
         seg_slide_postprocess(torch.zeros(1, 1, 19, 4, 4), [0], [0], (16, 16), (16, 16))                       # CPU tensor
     with pytest.raises(_lib.DdpError, match='gap|cover'):
         seg_slide_postprocess(torch.zeros(2, 1, 19, 4, 4).cuda(), [0], [0, 20], (16, 16), (16, 40))           # columns 16..19 uncovered
-    with pytest.raises(_lib.DdpError, match='more than 3'):
-        seg_slide_postprocess(torch.zeros(5, 1, 19, 4, 4).cuda(), [0], [0, 2, 4, 6, 8], (16, 16), (16, 24))   # stride < crop / 3
+    with pytest.raises(_lib.DdpError, match='more than 4'):
+        seg_slide_postprocess(torch.zeros(7, 1, 19, 4, 4).cuda(), [0], [0, 2, 4, 6, 8, 10, 12], (16, 16), (16, 28))   # stride < crop / 4
+    # four-fold overlap: the last window clamped back into the image - crop 9, stride 3, H = 16 -> origins 0, 3, 6, 7,
+    # pixels 7 and 8 lie under all four - is a grid the reference accepts; against the oracle's slide_inference
+    ys4, xs4, crop4 = slide_windows((16, 20), (9, 9), (3, 5))
+    assert ys4 == [0, 3, 6, 7] and crop4 == (9, 9)
+    sc4 = [synthetic.make_scores(1, 19, 3, 3, 700 + i) for i in range(len(ys4) * len(xs4))]
+    raw4 = seg_slide_postprocess(torch.stack(sc4).cuda(), ys4, xs4, crop4, (16, 20), want='scores').cpu()
+    assert max_rel(raw4, O.seg_slide_inference(sc4, ys4, xs4, crop4, (16, 20))) < 2e-6
     with pytest.raises(ValueError):
         seg_slide_postprocess(torch.zeros(3, 1, 19, 4, 4).cuda(), [0], [0, 8], (16, 16), (16, 24))            # 3 score maps for 2 windows
 

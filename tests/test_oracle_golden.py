@@ -77,7 +77,8 @@ def test_depth_golden(name):
     trace = []
     out = O.sample_depth(x, noise, sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'],
                          bit_scale=cfg['bit_scale'], min_depth=cfg['min_depth'], max_depth=cfg['max_depth'],
-                         time_difference=cfg.get('time_difference', 1), trace=trace)
+                         time_difference=cfg.get('time_difference', 1), trace=trace, scale_up=cfg.get('scale_up', False),
+                         use_eps=cfg.get('use_eps', True))
     assert max_rel(trace[0]['feat'], g['feat_step0']) < TOL
     for s in range(cfg['timesteps']):
         assert max_rel(trace[s]['depth_pred'], g['depth_pred_steps'][s]) < 5 * TOL, s
