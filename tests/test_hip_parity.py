@@ -421,7 +421,7 @@ def test_slide_epilogue_cityscapes_size_and_errors():
     # pixels 7 and 8 lie under all four - is a grid the reference accepts; against the oracle's slide_inference
     ys4, xs4, crop4 = slide_windows((16, 20), (9, 9), (3, 5))
     assert ys4 == [0, 3, 6, 7] and crop4 == (9, 9)
-    sc4 = [synthetic.make_scores(1, 19, 3, 3, 700 + i) for i in range(len(ys4) * len(xs4))]
+    sc4 = [synthetic.make_scores(1, 19, 4, 4, 700 + i) for i in range(len(ys4) * len(xs4))]      # (16-byte aligned window maps)
     raw4 = seg_slide_postprocess(torch.stack(sc4).cuda(), ys4, xs4, crop4, (16, 20), want='scores').cpu()
     assert max_rel(raw4, O.seg_slide_inference(sc4, ys4, xs4, crop4, (16, 20))) < 2e-6
     with pytest.raises(ValueError):
