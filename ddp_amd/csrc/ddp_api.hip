@@ -268,7 +268,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->py[l] = on ? cv.take(size_t(o->hh) * 96) : nullptr;
     o->px[l] = on ? cv.take(size_t(o->wh) * 96) : nullptr;
   }
-  o->xproj = cv.take(size_t(o->B) * o->N * 256);
+  o->xproj = cv.take((size_t(o->B) * o->N + 127) / 128 * 128 * 256);      // (whole tiles: the first step's head may write it fragment-major)
   o->mask = cv.take(o->M0 * (c->task == DDP_TASK_DEPTH ? 1 : 256));
   o->pred = cv.take(c->task == DDP_TASK_DEPTH ? o->M0 : 0);
   o->feat0 = cv.take(c->task == DDP_TASK_BEV ? o->M0 * 256 : 0);
@@ -880,8 +880,10 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         pl.px = o.px[0];
         pl.n_tok = o.Nh;
         pl.w = o.wh;
+        pl.res_frag = 0;
         if (head7) {
           pl.mask_sb = nullptr;
+          pl.res_frag = 1;
           pl.stream = o.head7_stream;
           DDP_TRY(launch_b3_head_nchw(pl, d_noise, d_x, weights->transform_b, st));
         } else {
@@ -915,6 +917,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
         tl.tlut = o.tlut;
         tl.res = o.xproj;
         tl.res_rn = o.r > 1 ? o.r * o.N : 0;
+        // written fragment-major by the first step's head (k_layer MODE 7): one coalesced 1-KiB load per (t, g) in the tail instead of
+        // 32 rows x 32 B (same box: head 0.62 -> 0.59 ms, tail -0.006 ms, +0.15 % on the batch; profiles/r05h_ab_xproj_frag.txt)
+        tl.res_frag = head7 ? 1 : 0;
         tl.v_out = o.vpad;
         tl.samp_out = o.samp;
         tl.py = o.py[0];

@@ -224,6 +224,7 @@ int launch_b3_tail(const TailLaunch& a, hipStream_t st) {
     la.tlut = a.tlut;
     la.res = a.res;
     la.res_rn = a.res_rn;
+    la.res_frag = a.res_frag;
     la.has_next = 1;
     la.v_out = a.v_out;
     la.samp_out = a.samp_out;

@@ -134,6 +134,7 @@ struct TailLaunch {
   const float* tlut;
   const float* res;
   int res_rn;
+  int res_frag;                 // res is fragment-major (written by launch_b3_head_nchw with res_frag)
   float* v_out;
   float* samp_out;
   const float *py, *px;
@@ -156,6 +157,7 @@ struct PrologueLaunch {
   const float* bias_ext;           // zeros | value_proj bias at [1024, 1280) | zeros
   const float* res;                // xproj rows (W_x x + b)
   int res_rn;                      // r * N when r noisy maps share one x row block, else 0
+  int res_frag;                    // launch_b3_head_nchw: write xproj fragment-major (the tails that follow read it that way)
   float* ubuf;                     // optional out: u_0 = W_m . m_0 (fp32 fragment-major) for the fused tails that follow
   int M;
   float* v_out;                    // zero-padded value map

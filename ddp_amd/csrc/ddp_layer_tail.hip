@@ -87,6 +87,7 @@ int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsign
     la.tlut = t.tlut;
     la.res = t.res;
     la.res_rn = t.res_rn;
+    la.res_frag = t.res_frag;
     la.v_out = t.v_out;
     la.samp_out = t.samp_out;
     la.py = t.py;
@@ -115,6 +116,7 @@ int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const 
   la.stream = a.stream;
   la.bias_ext = a.bias_ext;
   la.res = a.res;
+  la.res_frag = a.res_frag;
   la.ubuf = a.ubuf;
   la.M = a.M;
   la.has_next = 1;

@@ -109,6 +109,8 @@ struct LayerArgs {
   // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
   const float* res;              // fp32 rows of 256 (the loop-invariant half of the concat-conv, bias included)
   int res_rn;                    // row(m) = res_rn ? (m / res_rn) * n_tok + m % n_tok : m   (r noisy maps share one x)
+  int res_frag;                  // MODE 4 / 6 / 7, res_rn == 0: res is fp32 FRAGMENT-major like Q (one coalesced 1-KiB load per (t, g) instead of
+                                 // 32 rows x 32 B per instruction); written that way by MODE 7
   // MODE 4 (seg tail of step s fused with the head of step s + 1) / MODE 2 (u out): the noisy map only ever enters the
   // loop through u_t = W_m . m_t, and the DDIM update is affine in (m_t, x0) with x0 one of K + 1 table rows, so
   //   u_{t+1} = ua . u_t + uc . (W_m . LUT)[argmax],   ua = sigma' / max(sigma, 1e-8),  uc = alpha' - alpha . ua
@@ -1096,7 +1098,14 @@ k_layer(LayerArgs la) {
       // xproj rows out (the loop-invariant half of the concat-conv: every later step's tail reads them), q = xproj + u_0
       {
         const int m = m_base + j;
-        if (m < M) {
+        if (la.res_frag) {                                      // fragment-major (whole 32-token groups: the buffer is padded)
+          float* rf = const_cast<float*>(la.res) + grp * 8192 + lane * 4;
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<f32x4*>(rf + t * 1024 + g * 256) = f32x4{acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+        } else if (m < M) {
           float* rp = const_cast<float*>(la.res) + size_t(m) * 256 + 4 * h;
 #pragma unroll
           for (int t = 0; t < 8; ++t)
@@ -1514,6 +1523,8 @@ k_layer(LayerArgs la) {
         int mr = m < M ? m : M - 1;
         const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
         const float* rp = la.res + row * 256 + 4 * h;
+        const float* rpf = la.res + grp * 8192 + lane * 4;                    // (res_frag: the accumulator layout, as Q)
+        const bool rfrag = la.res_frag != 0;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
           f32x4 uu[2][4], tt[2][4], xx[2][4];
@@ -1524,8 +1535,18 @@ k_layer(LayerArgs la) {
               const int t = qt * 2 + i;
               uu[i][g] = *reinterpret_cast<const f32x4*>(ub + t * 1024 + g * 256);
               tt[i][g] = *reinterpret_cast<const f32x4*>(trow + t * 32 + 8 * g);
-              xx[i][g] = *reinterpret_cast<const f32x4*>(rp + t * 32 + 8 * g);
             }
+          if (rfrag) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) xx[i][g] = *reinterpret_cast<const f32x4*>(rpf + (qt * 2 + i) * 1024 + g * 256);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) xx[i][g] = *reinterpret_cast<const f32x4*>(rp + (qt * 2 + i) * 32 + 8 * g);
+          }
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int t = qt * 2 + i;
