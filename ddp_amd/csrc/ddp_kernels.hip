@@ -393,7 +393,10 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // nearly every 8-token group has SOME corner outside even a +-6 px window, so a larger window only costs occupancy.  The mixed
 // path itself with the four points unrolled on DPP broadcasts: hipcc spills in the divergent region at the 85 registers three
 // blocks per CU allow; the same through flat loads (per-lane address = shared aperture or global, one instruction stream, 80
-// registers, no spill) 0.149 / 0.254 - slower than the rolled ds_bpermute loop below on the profile it was meant for.
+// registers, no spill) 0.149 / 0.254 - slower than the rolled ds_bpermute loop below on the profile it was meant for; per-point fma
+// chains with an LDS pass for every point and a batched global pass (two points' loads in flight) for the points outside the window:
+// 0.151 / 0.227 against 0.150 / 0.229 (profiles/r05i_*) - the out-of-window taps cost what they cost in the texture path, not in
+// the loop around them.
 #ifndef DDP_GL_HALO
 #define DDP_GL_HALO 3
 #endif
