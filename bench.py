@@ -165,10 +165,15 @@ def _gpu_numa_nodes(world):
     try:
         nodes = []
         for i in range(world):
-            bdf = torch.cuda.get_device_properties(i).pci_bus_id if hasattr(torch.cuda.get_device_properties(i), 'pci_bus_id') else None
-            if bdf is None:
+            p = torch.cuda.get_device_properties(i)
+            bus = getattr(p, 'pci_bus_id', None)
+            if bus is None:
                 return None, None
-            nodes.append(int(open(f'/sys/bus/pci/devices/{bdf.lower()}/numa_node').read()))
+            if isinstance(bus, str):                      # 'dddd:bb:dd.f'
+                bdf = bus.lower()
+            else:                                         # torch reports domain / bus / device as integers
+                bdf = f'{int(getattr(p, "pci_domain_id", 0)):04x}:{int(bus):02x}:{int(getattr(p, "pci_device_id", 0)):02x}.0'
+            nodes.append(int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read()))
         cpus = {}
         for n in set(nodes):
             if n < 0:
