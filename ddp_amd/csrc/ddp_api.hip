@@ -1500,8 +1500,9 @@ int ddp_neck_msm_workspace(int batch, const int* level_h, const int* level_w, si
 
 namespace {
 // the merging itself on fp32 fragment-major level inputs a[0..3] (see ddp_neck_msm)
+// (a_nchw: the level inputs are the caller's NCHW tensors, read in place by the stream GEMM - no layout conversion)
 int msm_core(const float* const* a_blk, const int* level_h, const int* level_w, int batch, const float* d_conv_w, const float* d_gn_w,
-             const float* d_gn_b, int align_corners, int flags, float* d_out, const MsmLayout& o, hipStream_t st) {
+             const float* d_gn_b, int align_corners, int flags, float* d_out, const MsmLayout& o, hipStream_t st, bool a_nchw = false) {
   const int N = level_h[0] * level_w[0];
   if (!(flags & DDP_NECK_WEIGHTS_READY))
     for (int l = 0; l < 4; ++l) {
@@ -1519,6 +1520,7 @@ int msm_core(const float* const* a_blk, const int* level_h, const int* level_w, 
     pr[l].bias = nullptr;
     pr[l].gn_partial = nullptr;                            // (GroupNorm acts on the SUM of the resized level outputs)
     pr[l].gn_N = 0;
+    pr[l].nchw_N = a_nchw ? level_h[l] * level_w[l] : 0;
   }
   DDP_TRY(launch_b3_sgemm(pr, 4, 0, 0, st));               // all four levels in one persistent launch
   const float* yl[3] = {o.y[1], o.y[2], o.y[3]};
@@ -1553,8 +1555,7 @@ int ddp_neck_msm(const float* const* d_levels, const int* level_h, const int* le
   // bilinear resize of (that level's 256-column block of the weight applied at the level's OWN resolution).  Levels 1..3 are
   // 4x / 16x / 64x smaller than level 0, so the contraction shrinks from 4 to 1.33 level-0 maps and the 1024-channel
   // concatenation (6 KiB per token as a split operand) is never built.
-  for (int l = 0; l < 4; ++l) DDP_TRY(launch_nchw_to_blk(d_levels[l], o.a[l], batch, 256, level_h[l] * level_w[l], st));
-  return msm_core(o.a, level_h, level_w, batch, d_conv_w, d_gn_w, d_gn_b, align_corners, flags, d_out, o, st);
+  return msm_core(d_levels, level_h, level_w, batch, d_conv_w, d_gn_w, d_gn_b, align_corners, flags, d_out, o, st, true);
 }
 
 namespace {
@@ -1656,8 +1657,8 @@ int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, f
   SgemmProblem pr[4];
   for (int l = 0; l < 4; ++l) {
     const ddp_fpn_level& v = levels[3 - l];
-    DDP_TRY(launch_nchw_to_blk(d_in[3 - l], o.a[3 - l], batch, v.in_channels, v.h * v.w, st));
-    pr[l].A = o.a[3 - l];
+    pr[l].A = d_in[3 - l];                                  // the backbone's NCHW level, read in place (k_layer MODE 5, nchw_N)
+    pr[l].nchw_N = v.h * v.w;
     pr[l].out = o.y[3 - l];
     pr[l].stream = o.lat_stream[3 - l];
     pr[l].M = batch * v.h * v.w;
@@ -1688,6 +1689,7 @@ int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, f
     pr[l].ns = 72;
     pr[l].conv_h = v.h;
     pr[l].conv_w = v.w;
+    pr[l].nchw_N = 0;
     pr[l].gn_N = v.h * v.w;
     pr[l].gn_partial = (v.h * v.w) % 32 == 0 ? o.partial[l] : nullptr;
   }
@@ -1884,6 +1886,7 @@ int fcn_head_tokens(const ddp_fcn_conv* convs, int num_convs, int dilation, cons
   SgemmProblem pr;
   pr.gn_partial = nullptr;
   pr.gn_N = 0;
+  pr.nchw_N = 0;
   pr.M = M;
   for (int i = 0; i < num_convs; ++i) {
     if (!prep) DDP_TRY(fcn_conv_prepare(convs[i], i, d_temb, o, o.stream, o.aff + 256, st));

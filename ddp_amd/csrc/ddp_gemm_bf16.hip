@@ -346,6 +346,11 @@ int launch_b3_sgemm(const SgemmProblem* pr, int n, int act, int conv_dil, hipStr
     g.bias = pr[i].bias;
     g.gn_partial = pr[i].gn_partial;
     g.gn_N = pr[i].gn_N;
+    g.nchw_N = pr[i].nchw_N;
+    if (g.nchw_N > 0 && (pr[i].conv_h > 0 || pr[i].M % g.nchw_N || ((size_t(pr[i].M) * 32 * pr[i].ns) >> 32))) {
+      set_error("b3 stream GEMM: NCHW operand needs a plain (1x1) problem of whole images below 2^32 elements");
+      return DDP_E_BADCFG;
+    }
     if (g.gn_partial && (g.gn_N < 32 || g.gn_N % 32 || pr[i].M % g.gn_N)) {
       set_error("b3 stream GEMM: fused GroupNorm statistics need tokens per image (%d) to be a multiple of 32", g.gn_N);
       return DDP_E_BADCFG;

@@ -197,6 +197,7 @@ struct SgemmProblem {
   const float* bias;            // optional (256 floats)
   double* gn_partial;           // optional: fused GroupNorm partial sums [image][token / 32][32 groups][2] (gn_N % 32 == 0)
   int gn_N;                     // tokens per image
+  int nchw_N;                   // > 0: A is an NCHW tensor (images of nchw_N tokens, 32 * ns channels), read in place (no conv view)
 };
 int launch_b3_sgemm(const SgemmProblem* pr, int n, int act, int conv_dil, hipStream_t st);
 size_t b3_stage_bytes();

@@ -143,6 +143,8 @@ struct LayerArgs {
     double* gn_partial;      // optional: GroupNorm(32 groups of 8 channels) partial sums of the result, [image][token / 32][group]
                              // {sum, sum of squares} - one entry per wave; needs gn_N % 32 == 0 (a wave's 32 tokens in one image)
     int M, ns, tile0, conv_h, conv_w, gn_N;
+    int nchw_N;              // > 0: A is the caller's NCHW tensor (images of nchw_N tokens, 32 * ns channel planes): the fragments
+                             // are read from the planes as MODE 7 reads x (16 coalesced dword loads per stage), no layout conversion
   } gp[4];
   int g_tiles, g_act, conv_dil;
   unsigned long long* stamps;    // -DDDP_LYR_STAMP builds only (scripts/stamp_layer.py): per (block, wave) cycle sums of the phases
@@ -723,7 +725,29 @@ k_layer(LayerArgs la) {
       // stage's first MFMA; at one wave per SIMD all of them exposed)
       const float* tap_ptr = abase;
       bool tap_ok = false;
+      // NCHW source (FPN laterals straight from the backbone's levels): this lane's token in the planes, as in MODE 7
+      int nN = la.gp[pi].nchw_N;
+      asm volatile("" : "+s"(nN));
+      unsigned nchw_off5 = 0;
+      if (nN > 0) {
+        const int mm = mvalid ? m : Mp - 1;
+        const int img5 = mm / nN;
+        nchw_off5 = unsigned((img5 * (32 * ns) + 4 * h) * nN + (mm - img5 * nN));
+      }
       auto a_load = [&](int st, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+        if (nN > 0) {                                          // (uniform)
+          const float* p = abase + size_t(32 * st) * nN + nchw_off5;
+          const size_t nstr = size_t(nN);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              asm volatile("" : "+v"(p));
+              dst[g][e] = *p;
+              p += e == 3 ? 5 * nstr : nstr;
+            }
+          return;
+        }
         const float* ap = arow + size_t(st) * 1024;
         bool ok = true;
         if (ch > 0) {
