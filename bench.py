@@ -59,6 +59,12 @@ WORKLOADS = {
                                     bit_scale=0.01, accumulation=False, num_layers=5, feat_channels=512,
                                     bev_input_scope=[[-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8]],
                                     bev_output_scope=[[-50, 50, 0.5], [-50, 50, 0.5]]),
+    # the same head with the SHIPPED sampler setting (bev/configs/nuscenes/seg/ddp-fusion-bev256d2-lss-scale001-d5-lr5e-5.yaml:5
+    # randsteps: 4): 2 samples x 4 noise replicas = the token count of the workload above
+    'bev_fusion_k3_r4_2x200x200': dict(task='bev', batch=2, h=128, w=128, timesteps=3, randsteps=4, num_classes=6,
+                                       bit_scale=0.01, accumulation=False, num_layers=5, feat_channels=512,
+                                       bev_input_scope=[[-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8]],
+                                       bev_output_scope=[[-50, 50, 0.5], [-50, 50, 0.5]]),
 }
 # --scaling strong: the configuration's TOTAL batch (BASELINE.json configs[1..4]) is split over the ranks
 TOTAL_BATCH = {'ade_swin_t_k3_8x512x1024': 8, 'city_swin_l_k10_4x1024x2048': 32, 'kitti_depth_k20_16x352x1216': 16,

@@ -396,7 +396,9 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // registers, no spill) 0.149 / 0.254 - slower than the rolled ds_bpermute loop below on the profile it was meant for; per-point fma
 // chains with an LDS pass for every point and a batched global pass (two points' loads in flight) for the points outside the window:
 // 0.151 / 0.227 against 0.150 / 0.229 (profiles/r05i_*) - the out-of-window taps cost what they cost in the texture path, not in
-// the loop around them.
+// the loop around them.  Tile / halo pairs at 256 threads (profiles/r05l_*): 8x8 + halo 5 0.203 / 0.284, 8x8 + halo 4 0.182 / 0.260,
+// 8x16 + halo 4 0.189 / 0.257 against 0.152 / 0.232: the shipped shape is the fastest on BOTH profiles, so there is nothing for a
+// spread-adaptive window choice to pick from.
 #ifndef DDP_GL_HALO
 #define DDP_GL_HALO 3
 #endif
@@ -1974,16 +1976,22 @@ int launch_depth_aug_postprocess(const ddp_depth_aug* augs, int n_aug, int B, in
 }
 int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned short* out_sb, float* out_f32_blk, int rows, int n_tok,
                               int h, int w, const float* tab_y, const float* tab_x, int zero_guess, hipStream_t st) {
-  constexpr int TH = 8, TW = 16, NT = GL_THREADS;
+#ifndef DDP_GL_TH
+#define DDP_GL_TH 8
+#define DDP_GL_TW 16
+#define DDP_GL_NT GL_THREADS
+#define DDP_GL_MINW (DDP_GL_HALO <= 3 ? 6 : 4)
+#endif
+  constexpr int TH = DDP_GL_TH, TW = DDP_GL_TW, NT = DDP_GL_NT;
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
   const int n_tiles = (rows / n_tok) * tiles_x * tiles_y;
   prof_begin(TAG_GATHER, st);
   if (out_f32_blk)
-    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_HALO <= 3 ? 6 : 4, NT, true>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp,
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_MINW, NT, true>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp,
                        reinterpret_cast<unsigned short*>(out_f32_blk), n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x,
                        zero_guess);
   else
-    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_HALO <= 3 ? 6 : 4, NT, false>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
+    hipLaunchKernelGGL((k_msda_gather_lds<TH, TW, DDP_GL_HALO, DDP_GL_MINW, NT, false>), dim3(n_tiles * 8), dim3(NT), 0, st, vpad, samp, out_sb,
                        n_tok, h, w, tiles_x, tiles_y, n_tiles, rows, tab_y, tab_x, zero_guess);
   prof_end(TAG_GATHER, st);
   return check_launch("k_msda_gather_lds");

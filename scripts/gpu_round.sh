@@ -69,6 +69,6 @@ timeout 300 python scripts/power_calibration.py --components --seconds 3 > $OUT/
 f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -30 "$f"
 python scripts/collect_profiles.py $TAG --print-only
-# quick mode: the measurements first, the tests last
-[ "$QUICK" = quick ] && run_tests
+# quick mode: the measurements first, the tests last (SKIP_TESTS=1: the caller runs the full suite itself)
+[ "$QUICK" = quick ] && [ -z "${SKIP_TESTS:-}" ] && run_tests
 exit 0
