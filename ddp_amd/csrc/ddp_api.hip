@@ -283,8 +283,10 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   if (xt > hb) hb = xt;
   o->hbuf = cv.take(hb);
   o->xtok = o->hbuf;  // x in token-major form is dead once xproj exists
-  o->logits = cv.take(o->M * o->ldl);
-  o->prob = cv.take(o->M * o->ldl);
+  // (seg: the layer kernel's tails keep scores / probabilities fragment-major: whole 32-token groups x whole 64-class chunks)
+  const size_t pfl = c->task == DDP_TASK_SEG ? (o->M + 31) / 32 * 32 * size_t((o->Kc + 63) / 64 * 64) : 0;
+  o->logits = cv.take(o->M * o->ldl > pfl ? o->M * o->ldl : pfl);
+  o->prob = cv.take(o->M * o->ldl > pfl ? o->M * o->ldl : pfl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
   o->x0_trace = reinterpret_cast<unsigned char*>(
       cv.take((c->flags & (DDP_FLAG_RECORD_X0 | DDP_FLAG_FORCE_X0)) && c->task == DDP_TASK_SEG
@@ -1017,9 +1019,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // reduction over (steps x r) and token-major -> NCHW (ddp.py:243-245)
   if (cfg->task == DDP_TASK_SEG) {
     if (cfg->accumulation)
-      DDP_TRY(launch_finalize_nchw(o.prob, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r * o.K), st));
+      DDP_TRY(launch_finalize_nchw(o.prob, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r * o.K), st, seg_tail ? (o.Kc + 63) / 64 : 0));
     else
-      DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r), st));
+      DDP_TRY(launch_finalize_nchw(o.logits, o.ldl, d_out, o.B, o.r, o.Nh, o.Kc, float(o.r), st, seg_tail ? (o.Kc + 63) / 64 : 0));
   } else if (cfg->task == DDP_TASK_DEPTH) {
     DDP_TRY(launch_mean_r(o.pred, d_out, o.B, o.r, o.N, st));
   } else {

@@ -292,8 +292,9 @@ int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, i
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,
                     const float* conv_bias, const float* film, float* scale, float* shift, hipStream_t st);
 // out[b][k][n] = (1/div) * sum_ri prob[(b*r+ri)*N + n][k]
+// frag_nch > 0: prob is fragment-major as the layer kernel's seg tails write it (per 32-token group frag_nch * 2048 floats)
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
-                         hipStream_t st);
+                         hipStream_t st, int frag_nch = 0);
 // depth
 int launch_feat_depth(const float* xproj, const float* wm, const float* d, float* q, int B, int r, int N,
                       hipStream_t st);

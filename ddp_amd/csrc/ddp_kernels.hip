@@ -1670,9 +1670,15 @@ __global__ void __launch_bounds__(256) k_seg_x0_nchw(const float* __restrict__ s
   for (int c = 0; c < 256; ++c) op[size_t(c) * N] = (sigmoidf_(e[c]) * 2.0f - 1.0f) * bit_scale;
 }
 
+// where class k of token m lives: token-major rows (m, ldl), or - nch > 0, what the layer kernel's seg tails write - fragment-major:
+// per 32-token group [chunk k / 64][t][g][lane 64][4] = nch * 2048 floats, class 64c + 32t + 8g + 4h + e of token j at lane h * 32 + j
+__device__ __forceinline__ size_t prob_off(size_t m, int k, int ldl, int nch) {
+  if (nch == 0) return m * size_t(ldl) + k;
+  return (m >> 5) * size_t(nch * 2048) + size_t(k >> 3) * 256 + (((k >> 2) & 1) * 32 + int(m & 31)) * 4 + (k & 3);
+}
 // out[b][k][n] = (sum_ri prob[(b*r+ri)*N + n][k]) / div ; block = 64 tokens, LDS transpose
 __global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__ prob, int ldl, float* __restrict__ out,
-                                                        int r, int N, int K, float div) {
+                                                        int r, int N, int K, float div, int nch) {
   extern __shared__ float tile[];  // [64][K+1]
   const int b = blockIdx.y;
   const int n0 = blockIdx.x * 64;
@@ -1682,7 +1688,7 @@ __global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__
     const int n = n0 + nn;
     float s = 0.f;
     if (n < N)
-      for (int ri = 0; ri < r; ++ri) s += prob[(size_t(b * r + ri) * N + n) * ldl + k];
+      for (int ri = 0; ri < r; ++ri) s += prob[prob_off(size_t(b * r + ri) * N + n, k, ldl, nch)];
     tile[nn * ldt + k] = s / div;
   }
   __syncthreads();
@@ -1699,7 +1705,7 @@ __global__ void __launch_bounds__(256) k_finalize_nchw(const float* __restrict__
 // writes 256-B pieces to K different planes per block and divides by a run-time K per element: 2.6 TB/s at C2.)
 constexpr int FIN_T = 256, FIN_K = 32, FIN_LD = FIN_T + 4;
 __global__ void __launch_bounds__(256) k_finalize_nchw_t(const float* __restrict__ prob, int ldl, float* __restrict__ out, int r, int N,
-                                                          int K, float div) {
+                                                          int K, float div, int nch) {
   __shared__ float tile[FIN_K][FIN_LD];
   const int b = blockIdx.z;
   const int k0 = blockIdx.y * FIN_K;
@@ -1711,7 +1717,8 @@ __global__ void __launch_bounds__(256) k_finalize_nchw_t(const float* __restrict
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
       for (int ri = 0; ri < r; ++ri) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(prob + (size_t(b * r + ri) * N + n) * ldl + k0 + 4 * q);
+        // (fragment-major: the 8 lanes of a token read its (g, h) pieces, 32 tokens of a pass 512-B runs)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(prob + prob_off(size_t(b * r + ri) * N + n, k0 + 4 * q, ldl, nch));
         s = ri == 0 ? v : s + v;
       }
     }
@@ -2120,15 +2127,15 @@ int launch_seg_x0_nchw(const float* scores, const float* emb, float* out, int B,
   return check_launch("k_seg_x0_nchw");
 }
 int launch_finalize_nchw(const float* prob, int ldl, float* out, int B, int r, int N, int K, float div,
-                         hipStream_t st) {
-  if (N % 4 == 0 && ldl % 32 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    hipLaunchKernelGGL(k_finalize_nchw_t, dim3(cdiv(N, FIN_T), cdiv(K, FIN_K), B), dim3(256), 0, st, prob, ldl, out, r, N, K, div);
+                         hipStream_t st, int frag_nch) {
+  if (N % 4 == 0 && (ldl % 32 == 0 || frag_nch) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(k_finalize_nchw_t, dim3(cdiv(N, FIN_T), cdiv(K, FIN_K), B), dim3(256), 0, st, prob, ldl, out, r, N, K, div, frag_nch);
     return check_launch("k_finalize_nchw_t");
   }
   const size_t lds = size_t(64) * (K + 1) * sizeof(float);
   static LdsAttrOnce attr;
   attr.ensure(reinterpret_cast<const void*>(&k_finalize_nchw), 64 * 257 * int(sizeof(float)));
-  hipLaunchKernelGGL(k_finalize_nchw, dim3(cdiv(N, 64), B), dim3(256), lds, st, prob, ldl, out, r, N, K, div);
+  hipLaunchKernelGGL(k_finalize_nchw, dim3(cdiv(N, 64), B), dim3(256), lds, st, prob, ldl, out, r, N, K, div, frag_nch);
   return check_launch("k_finalize_nchw");
 }
 int launch_feat_depth(const float* xproj, const float* wm, const float* d, float* q, int B, int r, int N,

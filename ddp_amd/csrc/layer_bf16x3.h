@@ -100,7 +100,9 @@ struct LayerArgs {
   int n_tok, w;
   // MODE 1 (seg tail): conv_seg + x0 projection + DDIM update + softmax accumulation on the tokens of Q
   const float* lut;              // (num_classes + 1, 256): (sigmoid(embedding) * 2 - 1) * bit_scale
-  float* prob;                   // (M, ldl) accumulated softmax / last-step scores
+  float* prob;                   // accumulated softmax / last-step scores, FRAGMENT-major: per 32-token group [chunk c][t][g][lane 64][4]
+                                 // = NCH * 2048 floats (class 64c + 32t + 8g + 4h + e of token j at lane h * 32 + j): every access of the
+                                 // tails is one coalesced 1-KiB instruction (token-major rows: 32 rows x 32 B per instruction)
   unsigned short* mask_sb;       // SB noisy map m_t (256 ch): read, replaced by m_{t_next}
   unsigned char* x0_idx;         // optional (DDP_FLAG_RECORD_X0): the step's argmax class per token
   const unsigned char* x0_force; // FORCE instantiations (DDP_FLAG_FORCE_X0): the class fed back INSTEAD of the argmax
@@ -1476,7 +1478,7 @@ k_layer(LayerArgs la) {
       // wait, compute, store 3 - sixteen times; load, wait, add, store - 24 times on the accumulated probabilities) pay a
       // full memory round trip per iteration at one wave per SIMD: vector memory completes in order, vmcnt counts stores
       // too, and the LUT loads may not move above the map stores they could alias.
-      float* pr = la.prob + size_t(valid ? m : 0) * la.ldl + 4 * h;
+      float* pr = la.prob + grp * size_t(NCH * 2048) + lane * 4;           // + ((2 c + t) * 4 + g) * 256
       char* ms = reinterpret_cast<char*>(la.mask_sb) + grp * 256 * 192 + lane * 16;
       if (la.prob_mode == 1 || la.prob_mode == 2) {          // softmax over the classes, accumulated over the steps
         float ssum = 0.f;
@@ -1510,8 +1512,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int cls0 = c * 64 + t * 32 + 8 * g;
-              // columns past the row (ldl >= roundup(K, 32)) are never used: read column 0 instead
-              old[c][t][g] = *reinterpret_cast<const f32x4*>(cls0 + 4 * h < K ? pr + cls0 : pr);
+              old[c][t][g] = *reinterpret_cast<const f32x4*>(pr + ((2 * c + t) * 4 + g) * 256);        // (whole chunks are allocated)
             }
       }
       if (accumulate) {
@@ -1530,8 +1531,8 @@ k_layer(LayerArgs la) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int cls0 = c * 64 + t * 32 + 8 * g;
-              if (cls0 + 4 * h < K)                            // (rows are padded to ldl >= roundup(K, 32))
-                *reinterpret_cast<f32x4*>(pr + cls0) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
+              if (cls0 < K)                                     // (uniform: whole 1-KiB pieces; classes past K are never read back)
+                *reinterpret_cast<f32x4*>(pr + ((2 * c + t) * 4 + g) * 256) = f32x4{lg[c][t][4 * g], lg[c][t][4 * g + 1], lg[c][t][4 * g + 2], lg[c][t][4 * g + 3]};
             }
       }
       // MODE 6 after the LAST step: nothing to update, no next head.  One uniform exit instead of two conditions (this one and
