@@ -398,7 +398,8 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 // 0.151 / 0.227 against 0.150 / 0.229 (profiles/r05i_*) - the out-of-window taps cost what they cost in the texture path, not in
 // the loop around them.  Tile / halo pairs at 256 threads (profiles/r05l_*): 8x8 + halo 5 0.203 / 0.284, 8x8 + halo 4 0.182 / 0.260,
 // 8x16 + halo 4 0.189 / 0.257 against 0.152 / 0.232: the shipped shape is the fastest on BOTH profiles, so there is nothing for a
-// spread-adaptive window choice to pick from.
+// spread-adaptive window choice to pick from.  Tile ORDER in super-columns of 8 / 4 / 2 tiles (the tile below 8 blocks away instead of
+// tiles_x): 0.322 against 0.310 ms at Cityscapes size, 0.155-0.161 against 0.153 at C2 (profiles/r05n_*) - raster order stays.
 #ifndef DDP_GL_HALO
 #define DDP_GL_HALO 3
 #endif

@@ -1510,10 +1510,8 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int cls0 = c * 64 + t * 32 + 8 * g;
+            for (int g = 0; g < 4; ++g)
               old[c][t][g] = *reinterpret_cast<const f32x4*>(pr + ((2 * c + t) * 4 + g) * 256);        // (whole chunks are allocated)
-            }
       }
       if (accumulate) {
 #pragma unroll
