@@ -3,8 +3,10 @@
 
 Run by hand in the build container (needs /root/reference):
 
-    python tests/golden/gen_golden.py            # all tasks, one subprocess each
+    python tests/golden/gen_golden.py            # all tasks, one subprocess each (~1 min)
     python tests/golden/gen_golden.py --task seg
+    python tests/golden/gen_golden.py --task fullsize   # NOT part of 'all' (~3 min): the reference at the sizes of BASELINE.json's
+                                                        # configurations (full_c1 .. full_c5_r4), see FULLSIZE_* below
 
 The reference packages are imported through ``ref_shim`` (mmcv 1.3.17 python bricks vendored in
 the reference tree, torch CPU fp32), the seeded synthetic hot-path weights of
