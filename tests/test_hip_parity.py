@@ -271,6 +271,18 @@ def test_sample_golden(dev, name, variant):
     assert err < REL < GATE
 
 
+@pytest.mark.parametrize('name', ['seg_ade_k3', 'seg_city_k10', 'seg_td2'])
+def test_fused_and_unfused_tail_same_bits(dev, name):
+    """k_layer MODE 6 (last layer of a step + seg tail + next head in ONE kernel) against the two kernels it was fused from
+    (DDP_FLAG_UNFUSED_TAIL: MODE 0 + MODE 4 / MODE 1): the same contractions in the same order, the layer output merely stays in
+    registers - the outputs must be bit-identical (150 and 19 classes, accumulation on and off, r = 1 and 2)."""
+    cfg, sd, x, noise, step_noise, g = load_case(name)
+    dx, dn = x.to(dev), noise.unsqueeze(0).contiguous().to(dev)
+    a = _engine(cfg, sd, dev, fused_tail=True).sample(dx, dn).clone()
+    b = _engine(cfg, sd, dev, fused_tail=False).sample(dx, dn)
+    assert torch.equal(a, b)
+
+
 def test_sample_batch_matches_per_image_oracle(dev):
     """B=3 images in ONE call (what the reference cannot do: its loop is b=1) == three independent
     oracle runs, each with its own noise."""
