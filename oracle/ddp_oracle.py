@@ -442,7 +442,7 @@ def bev_grid_transform(feat, input_scope=((-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8)
     u, v = torch.meshgrid(coords, indexing='ij')
     grid = torch.stack([v, u], dim=-1)
     grid = torch.stack([grid] * feat.shape[0], dim=0)
-    return F.grid_sample(feat, grid, mode='bilinear', align_corners=False)
+    return F.grid_sample(feat, grid.to(feat.dtype), mode='bilinear', align_corners=False)   # (no-op in fp32; the fp64 diagnostic)
 
 
 def head_forward_bev(feat, temb, sd, core='gridsample', **scopes):
