@@ -668,7 +668,9 @@ def main():
     require_devices(world)
     dist_on = world > 1 or args.force_dist
     # N > 1: every rank (and the loader workers / intra-op threads it spawns) on its own cores, near its GPU when the box says
-    pinned = pin_rank(local_rank, world) if (world > 1 and not args.no_pin) else None
+    # (the split is over the ranks of THIS node: LOCAL_WORLD_SIZE under torchrun, never more than the visible devices)
+    local_world = max(1, min(int(os.environ.get('LOCAL_WORLD_SIZE', world)), world, torch.cuda.device_count() or world))
+    pinned = pin_rank(local_rank, local_world) if (world > 1 and not args.no_pin) else None
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:

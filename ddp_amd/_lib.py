@@ -108,6 +108,10 @@ def load(path=None):
     if not os.path.exists(path):
         raise DdpError(f'{path} not found: build it with `python -m ddp_amd.build` '
                        '(hipcc --offload-arch=gfx950); ddp_amd has no non-HIP fallback')
+    if path == os.path.abspath(_build.LIB_PATH) and _build.built_hash() != _build.source_hash():
+        # the in-tree library is git-ignored: a checkout / snapshot may carry one built from OTHER sources
+        raise DdpError(f'{path} is stale: built from sources {_build.built_hash() or "<no stamp>"}, the tree holds '
+                       f'{_build.source_hash()}; rebuild with `python -m ddp_amd.build`')
     lib = C.CDLL(path)
     lib.ddp_last_error.restype = C.c_char_p
     lib.ddp_abi_version.restype = C.c_int

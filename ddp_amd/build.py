@@ -30,18 +30,30 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+STAMP_PATH = os.path.join(LIB_DIR, '.source_sha')
+
+
+def built_hash():
+    """source_hash() of the sources the .so in lib/ was built from ('' when there is no stamp)."""
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().strip()
+    except OSError:
+        return ''
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    # by CONTENT, not by mtime: after a fresh checkout (or a gpurun snapshot) mtimes are arbitrary, and the .so is git-ignored
+    return not os.path.exists(LIB_PATH) or built_hash() != source_hash()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    sha = source_hash()                  # hashed BEFORE compiling: an edit during the build leaves a stale stamp, i.e. a rebuild
+    if os.path.exists(STAMP_PATH):
+        os.remove(STAMP_PATH)
     objs = []
     procs = []
     for s in SOURCES:
@@ -59,6 +71,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP_PATH, 'w') as f:
+        f.write(sha + '\n')
     return LIB_PATH
 
 

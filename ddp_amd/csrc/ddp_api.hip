@@ -100,7 +100,8 @@ struct Layout {
   unsigned char* pro_stream;                            // step prologue: W_m (8 wide) + layer 0's value / sampling proj (11 tall)
   float* pro_bias;                                      //                layer 0's value_proj bias at [1024, 1280)
   float* ubuf;                                          // u = W_m . m_t, fp32 fragment-major (fused seg tails)
-  float* tlut;                                          // (Kc + 1, 256) = W_m . LUT^T
+  float* tlut;                                          // seg: (Kc + 1, 256) = LUT . W_m^T; bev (<= 8 classes): (2^Kc, 256) = LUT64 . W_m^T
+  float* lut64;                                         // bev (<= 8 classes): the 2^Kc x0 vectors of a pixel
   unsigned char* tail4_stream;                          // fused tail: conv_seg images + layer 0's 11 projection images
   unsigned char* head7_stream;                          // first step's head from NCHW (k_layer MODE 7): W_m 8 wide + W_x 8 wide + 11
   unsigned char* lt_stream;                             // last layer + tail (k_layer MODE 6): 72 stages of layer L-1 + tail4_stream
@@ -156,6 +157,14 @@ int validate(const ddp_cfg* c) {
   if (c->flags & ~(DDP_FLAG_UNFUSED_LAYER | DDP_FLAG_UNFUSED_PROLOGUE | DDP_FLAG_RECORD_X0 | DDP_FLAG_GATHER_GUESS_ZERO |
                    DDP_FLAG_FORCE_X0 | DDP_FLAG_UNFUSED_TAIL | DDP_FLAG_SB_HEAD | DDP_FLAG_DEPTH_SCALE_UP | DDP_FLAG_DEPTH_NO_EPS)) {
     set_error("unknown flags 0x%x", c->flags);
+    return DDP_E_BADCFG;
+  }
+  if ((c->flags & (DDP_FLAG_FORCE_X0 | DDP_FLAG_RECORD_X0)) && c->task != DDP_TASK_SEG) {
+    set_error("DDP_FLAG_RECORD_X0 / DDP_FLAG_FORCE_X0 exist for the segmentation sampler only (task %d)", c->task);
+    return DDP_E_BADCFG;
+  }
+  if ((c->flags & (DDP_FLAG_DEPTH_SCALE_UP | DDP_FLAG_DEPTH_NO_EPS)) && c->task != DDP_TASK_DEPTH) {
+    set_error("DDP_FLAG_DEPTH_* configure the depth head only (task %d)", c->task);
     return DDP_E_BADCFG;
   }
   if (c->gemm_mode != DDP_GEMM_F32_MFMA && c->gemm_mode != DDP_GEMM_BF16X3) {
@@ -245,10 +254,13 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->tail4_stream = reinterpret_cast<unsigned char*>(cv.take(segp ? size_t(8 + 11) * 48 * 1024 / sizeof(float) : 0));
     o->tail4_bias = cv.take(segp ? size_t(b3_layer_bias_floats()) : 0);
     o->head7_stream = (segp && o->Cx == 256) ? reinterpret_cast<unsigned char*>(cv.take(size_t(8 + 8 + 11) * 48 * 1024 / sizeof(float))) : nullptr;
-    const bool lt = segp && o->L >= 1 && b3_layer_tail_supported(o->Kc);
-    o->lt_stream = lt ? reinterpret_cast<unsigned char*>(cv.take(size_t(72 + 8 + 11) * 48 * 1024 / sizeof(float))) : nullptr;
+    // last layer + tail (k_layer MODE 6 / 8 / 9): seg 72 + 2 * chunks + 11 images, bev (<= 32 classes) and depth (9 taps) 72 + 2
+    const bool lt = o->L >= 1 && (segp ? b3_layer_tail_supported(o->Kc) : o->Kc <= 32);
+    o->lt_stream = lt ? reinterpret_cast<unsigned char*>(cv.take(size_t(segp ? 72 + 8 + 11 : 72 + 2) * 48 * 1024 / sizeof(float))) : nullptr;
     o->lt_bias = lt ? cv.take(size_t(b3_layer_bias_floats())) : nullptr;
-    o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : 0);
+    const bool bev_tab = c->task == DDP_TASK_BEV && o->Kc <= 8;
+    o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : bev_tab ? (size_t(1) << o->Kc) * 256 : 0);
+    o->lut64 = bev_tab ? cv.take((size_t(1) << o->Kc) * 256) : nullptr;
   } else {
     o->tail_stream = nullptr;
     o->tail_bias = nullptr;
@@ -260,6 +272,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->lt_stream = nullptr;
     o->lt_bias = nullptr;
     o->tlut = nullptr;
+    o->lut64 = nullptr;
   }
   o->const_bytes = cv.off * sizeof(float);
   // ---- region B: everything that depends on the geometry (batch, r, map size): positional tables, activations
@@ -283,8 +296,9 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
   if (xt > hb) hb = xt;
   o->hbuf = cv.take(hb);
   o->xtok = o->hbuf;  // x in token-major form is dead once xproj exists
-  // (seg: the layer kernel's tails keep scores / probabilities fragment-major: whole 32-token groups x whole 64-class chunks)
-  const size_t pfl = c->task == DDP_TASK_SEG ? (o->M + 31) / 32 * 32 * size_t((o->Kc + 63) / 64 * 64) : 0;
+  // (seg: the layer kernel's tails keep scores / probabilities fragment-major: whole 128-token TILES x whole 64-class chunks -
+  // the wholly invalid waves of the last tile pre-load their groups' accumulators like every other wave)
+  const size_t pfl = c->task == DDP_TASK_SEG ? (o->M + 127) / 128 * 128 * size_t((o->Kc + 63) / 64 * 64) : 0;
   o->logits = cv.take(o->M * o->ldl > pfl ? o->M * o->ldl : pfl);
   o->prob = cv.take(o->M * o->ldl > pfl ? o->M * o->ldl : pfl);
   o->snoise = cv.take(c->sampler == DDP_SAMPLER_DDPM ? o->M0 * 256 : 0);
@@ -512,7 +526,30 @@ int prepare_model(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipSt
         }
       }
     }
-    if (o.lt_stream) {
+    if (o.lt_stream && c->task != DDP_TASK_SEG) {
+      // last layer + bev / depth tail (k_layer MODE 8 / 9): [layer L-1: 72 stages][the head convolution: 2 tall stages of <= 32 rows]
+      // (conv_seg of the bev head; the nine taps of the 3x3 conv_depth as nine output rows).  Bias table: fc1's; tail_bias: conv_seg's
+      // (depth: zeros - conv_depth's bias is added once per pixel by k_depth_update).
+      const size_t sb = size_t(48) * 1024;
+      const int rows = c->task == DDP_TASK_DEPTH ? 9 : o.Kc;
+      DDP_TRY(launch_build_stages(o.wp_head.p, o.wp_head.comp_stride, 256, rows, 1, 1, 2, 0, 0, 1, 2, o.tail_stream, st));
+      if (hipMemsetAsync(o.tail_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          (c->task == DDP_TASK_BEV && w->head_b &&
+           hipMemcpyAsync(o.tail_bias, w->head_b, size_t(o.Kc) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) ||
+          hipMemcpyAsync(o.lt_stream, o.wstream[o.L - 1], 72 * sb, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(o.lt_stream + 72 * sb, o.tail_stream, 2 * sb, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemsetAsync(o.lt_bias, 0, size_t(b3_layer_bias_floats()) * sizeof(float), st) != hipSuccess ||
+          hipMemcpyAsync(o.lt_bias, w->layers[o.L - 1].ffn0_b, DDP_FFN * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("layer + tail stream copy failed");
+        return DDP_E_LAUNCH;
+      }
+    }
+    if (o.lut64) {
+      // bev u chain: the 2^K x0 vectors of a pixel and their images under W_m (exact fp32 products, as the seg table)
+      DDP_TRY(launch_build_bev_lut(w->embedding, o.lut64, o.Kc, c->bit_scale, st));
+      DDP_TRY(launch_linear(o.lut64, 256, false, o.wm, 256, nullptr, nullptr, 0, 0, 0, o.tlut, 256, 1 << o.Kc, 256, 256, 0, st));
+    }
+    if (o.lt_stream && c->task == DDP_TASK_SEG) {
       // last layer + tail (k_layer MODE 6): the images do not depend on the step, so ONE concatenated stream serves every step -
       // [layer L-1: Wo 8 wide, 16 x (fc1 2 tall, fc2 2 wide)][conv_seg 2 tall per 64 classes][layer 0's Wv 8 tall][Wcat 2 tall +
       // 1 split-K]; after the last step the kernel wraps behind conv_seg.  Bias table: fc1's | layer 0's value_proj bias.
@@ -811,6 +848,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     // (the first step's head reads d_noise itself)
   } else if (seg_tail) {
     DDP_TRY(launch_nchw_to_sb(d_noise, o.in_sb, o.R, 256, o.N, st));    // the noisy map only ever exists as SB on this path
+  } else if (cfg->task == DDP_TASK_BEV && o.b3 && o.fused_layer && o.fused_pro && o.lt_stream && o.lut64 &&
+             !(cfg->flags & DDP_FLAG_UNFUSED_TAIL)) {
+    // (bev u chain - the condition `bev_chain` below: the start noise goes straight into u_0 = W_m . noise)
   } else {
     DDP_TRY(launch_nchw_to_tok(d_noise, o.mask, o.R, 256, o.N, st));
   }
@@ -824,6 +864,20 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // (q = W_x x + b + u', layer 0's projections): k_layer MODE 4.  Step 0 starts from the noise with the step-prologue
   // kernel, the last step's tail has nothing to update.
   const bool u_chain = seg_tail && pro_fused;
+  // bev / depth on the fused path: the step's LAST layer runs with the head convolution as its tail (k_layer MODE 8 / 9) - no head GEMM,
+  // no SB copy of the layer output.  bev with <= 8 classes additionally runs the u chain: the grid transform and the concat-conv are
+  // linear, so resample(W_x x + b) is hoisted out of the loop (rx, row-major in o.s: the fused layers never touch that buffer), the
+  // noisy map is carried as u = W_m m (o.feat0, row-major at the map size) and follows the DDIM update through the 2^K-row table
+  // T = LUT64 . W_m^T - per step: u update, q = rx + resample(u), layer 0's projections; no GEMM at the map size after u_0.
+  const bool lt_other = o.b3 && o.fused_layer && o.fused_pro && o.lt_stream && !(cfg->flags & DDP_FLAG_UNFUSED_TAIL);
+  const bool depth_lt = cfg->task == DDP_TASK_DEPTH && lt_other;
+  const bool bev_chain = cfg->task == DDP_TASK_BEV && lt_other && o.lut64;
+  if (bev_chain) {
+    DDP_TRY(launch_bev_resample(o.xproj, o.s, o.B, geom, st));                      // rx = resample(W_x x + b), B maps
+    DDP_TRY(launch_nchw_to_sb(d_noise, o.in_sb, o.R, 256, o.N, st));
+    DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, nullptr, 0, 0, 0, o.feat0, 256, M0, 256, 256, st, TAG_FEAT));   // u_0 = W_m . noise
+  }
+  unsigned char* bev_code = reinterpret_cast<unsigned char*>(o.logits);            // (M) the step's x0 code per head-grid token
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
@@ -853,8 +907,16 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       DDP_TRY(launch_feat_depth(o.xproj, o.wm, o.mask, o.s, o.B, o.r, o.N, st));
       DDP_TRY(publish_q(o, o.s, st));
     } else {
-      if (o.b3 && !seg_tail) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
-      if (cfg->task == DDP_TASK_BEV) {
+      if (o.b3 && !seg_tail && !bev_chain) DDP_TRY(launch_row_to_sb(o.mask, 256, o.in_sb, M0, 256, st));
+      if (bev_chain) {
+        if (s > 0) {
+          // m' = alpha' x0 + sigma' (m - alpha x0) / max(sigma, 1e-8) (fusion_models/ddp.py:296-297) under W_m, with the PREVIOUS step's scalars
+          const ddp_step& pp = steps[s - 1];
+          const float ua = pp.sigma_next / (pp.sigma > 1e-8f ? pp.sigma : 1e-8f);
+          DDP_TRY(launch_bev_u_update(o.feat0, bev_code, o.tlut, o.R, geom, ua, pp.alpha_next - pp.alpha * ua, st));
+        }
+        DDP_TRY(launch_bev_q(o.feat0, o.s, o.q, o.R, o.r, geom, st));
+      } else if (cfg->task == DDP_TASK_BEV) {
         if (o.b3)
           DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, o.xproj, 256, o.r * o.N, o.N, o.feat0, 256, M0, 256, 256, st,
                                    TAG_XPROJ));
@@ -943,9 +1005,22 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       tl.sigma_next = sp.sigma_next;
     }
     // u chain: the step's tail runs inside the LAST layer's kernel (k_layer MODE 6) - the layer output never leaves the registers
-    const bool lt_fused = seg_tail && u_chain && o.lt_stream && !(cfg->flags & DDP_FLAG_UNFUSED_TAIL);
-    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !seg_tail, lt_fused ? &tl : nullptr));
-    if (seg_tail) {
+    const bool lt_fused = (seg_tail && u_chain && o.lt_stream && !(cfg->flags & DDP_FLAG_UNFUSED_TAIL)) || depth_lt || bev_chain;
+    if (lt_fused && !seg_tail) {
+      tl.Q = o.q;
+      tl.M = M;
+      tl.num_classes = cfg->task == DDP_TASK_DEPTH ? 9 : o.Kc;
+      tl.kind = cfg->task == DDP_TASK_DEPTH ? 2 : 1;
+      tl.prob = cfg->task == DDP_TASK_DEPTH ? o.logits : o.prob;      // depth: the nine taps (rows of 32) k_depth_update sums
+      tl.prob_mode = cfg->task == DDP_TASK_DEPTH ? 3 : (s == 0 ? 1 : 2);
+      tl.threshold = cfg->threshold;
+      tl.x0_idx = bev_chain ? bev_code : nullptr;
+      tl.ldl = 32;
+    }
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !(seg_tail || lt_fused), lt_fused ? &tl : nullptr));
+    if (lt_fused && cfg->task == DDP_TASK_BEV) {
+      // (probabilities accumulated and the step's x0 codes written by the fused tail; the next step's head updates u from them)
+    } else if (seg_tail) {
       if (!lt_fused) DDP_TRY(launch_b3_tail(tl, st));
     } else if (cfg->task == DDP_TASK_SEG) {
       if (o.b3)
@@ -977,8 +1052,13 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       }
       DDP_TRY(launch_seg_update(a, st));
     } else if (cfg->task == DDP_TASK_DEPTH) {
-      if (o.b3) DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, st, TAG_HEAD));
-      else DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
+      if (depth_lt) {
+        // (the nine taps were written by the last layer's tail: k_layer MODE 9)
+      } else if (o.b3) {
+        DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, st, TAG_HEAD));
+      } else {
+        DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
+      }
       DepthUpdateArgs a;
       a.taps = o.logits;
       a.bias = 0.f;

@@ -139,13 +139,18 @@ struct TailLaunch {
   float* samp_out;
   const float *py, *px;
   int n_tok, w;
+  // launch_b3_layer_tail only - kind 1 (bev, k_layer MODE 8): prob = accumulated sigmoid maps, token-major rows of 32 (prob_mode 1 / 2),
+  // x0_idx = the step's code per token (bit k = sigmoid_k > threshold; num_classes <= 8) or nullptr; kind 2 (depth, MODE 9): prob = the
+  // nine per-tap dot products of conv_depth, token-major rows of 32.  No next-step head in either (fuse_next = 0).
+  int kind;
+  float threshold;
 };
 int launch_b3_tail(const TailLaunch& a, hipStream_t st);
 // the LAST decoder layer of a step and that step's seg tail as ONE kernel (k_layer MODE 6, ddp_layer_tail.hip): `t.Q`, the layer
 // output, never travels to HBM.  t.fuse_next as in launch_b3_tail (a next step follows) or the last step's plain tail; t.mask_sb
 // must be nullptr (u chain).  `stream` = 72 layer stages + t's stream; `bias_ext` = fc1 bias | layer 0's value_proj bias at
-// [1024, 1280); `seg_bias` = conv_seg's bias zero padded to 256 floats.  Built for 1..64 and 129..192 classes (Cityscapes, ADE):
-// b3_layer_tail_supported() says whether a class count is.
+// [1024, 1280); `seg_bias` = conv_seg's bias zero padded to 256 floats.  Built for 1..256 classes (b3_layer_tail_supported()).
+// t.kind 1 / 2: the bev / depth tails (k_layer MODE 8 / 9): `stream` = 72 layer stages + the head's 2 tall stages.
 bool b3_layer_tail_supported(int num_classes);
 int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsigned char* stream, const float* bias_ext,
                          const float* seg_bias, hipStream_t st);
@@ -330,5 +335,11 @@ struct BevUpdateArgs {
   ddp_step st;
 };
 int launch_bev_update(const BevUpdateArgs& a, hipStream_t st);
+// the bev sampler's u chain (ddp_kernels.hip: k_bev_q): q (fragment-major, R maps of hh x wh) = rx[map / r] + resample(u[map]);
+// the 2^K x0 vectors of a pixel; u <- ua u + uc T[code at the pixel's nearest head-grid source]
+int launch_bev_q(const float* u, const float* rx, float* q_blk, int R, int r, const BevGeom& g, hipStream_t st);
+int launch_build_bev_lut(const float* emb, float* lut, int K, float bit_scale, hipStream_t st);
+int launch_bev_u_update(float* u, const unsigned char* code, const float* tlut, int R, const BevGeom& g, float ua, float uc,
+                        hipStream_t st);
 
 }  // namespace ddp

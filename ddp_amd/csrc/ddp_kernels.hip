@@ -1830,6 +1830,68 @@ __global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ 
   *reinterpret_cast<f32x4*>(out + size_t(m) * 256 + lane * 4) = acc;   // row-major (published by publish_q)
 }
 
+// The BEV sampler's u chain (ddp_api.hip, bev/mmdet3d/models/fusion_models/ddp.py:268-301 with the linear operators regrouped): the grid
+// transform (bilinear grid_sample, zeros padding) and the 1x1 concat-conv are both linear, so
+//     resample(W_x x + b + W_m m_t) = resample(W_x x + b) + resample(u_t),   u_t = W_m m_t   (at the map size h x w)
+// - the first term is loop invariant, and u follows the DDIM update affinely because x0 is one of 2^K rows of a table (the
+// thresholded maps select a mean embedding, :290-295): u' = ua u + uc T[code], T = LUT . W_m^T.
+// q[(b r + ri) Nh + n] (fragment-major) = rx[b Nh + n] (row-major, shared by the r replicas) + resample(u[(b r + ri)])[n]
+__global__ void __launch_bounds__(256) k_bev_q(const float* __restrict__ u, const float* __restrict__ rx, float* __restrict__ q_blk, int R,
+                                                int r, BevGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Nh = g.hh * g.wh, N = g.h * g.w;
+  if (m >= R * Nh) return;
+  const int img = m / Nh, n = m - img * Nh;
+  const int oi = n / g.wh, oj = n - oi * g.wh;
+  const float y = bev_src_coord(g, 0, oi, g.h);
+  const float x = bev_src_coord(g, 1, oj, g.w);
+  const float xf = floorf(x), yf = floorf(y);
+  const float fx = x - xf, fy = y - yf;
+  const int x0 = int(xf), y0 = int(yf);
+  const float* base = u + size_t(img) * N * 256 + lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx, yy = y0 + dy;
+      if (xx >= 0 && xx < g.w && yy >= 0 && yy < g.h) {
+        const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
+        acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
+      }
+    }
+  acc += *reinterpret_cast<const f32x4*>(rx + (size_t(img / r) * Nh + n) * 256 + lane * 4);
+  *reinterpret_cast<f32x4*>(q_blk + blk_off256(m, lane * 4)) = acc;
+}
+
+// LUT64[code][c] = (sigmoid(mean_k E[bit k of code ? k + 1 : 0][c]) * 2 - 1) * bit_scale: the 2^K values x0 can take at a pixel
+// (fusion_models/ddp.py:291-295; the sum in class order, as k_bev_update forms it)
+__global__ void k_build_bev_lut(const float* __restrict__ emb, float* __restrict__ lut, int K, float bit_scale) {
+  const int code = blockIdx.x, c = threadIdx.x;
+  float e = 0.f;
+  for (int k = 0; k < K; ++k) e += emb[size_t(((code >> k) & 1) ? k + 1 : 0) * 256 + c];
+  lut[size_t(code) * 256 + c] = (sigmoidf_(e / float(K)) * 2.0f - 1.0f) * bit_scale;
+}
+
+// u[(img, i, j)] = ua u + uc T[code[(img, nearest source of (i, j) in the head grid)]]   (F.interpolate(mode='nearest') of the
+// thresholded maps, :293: src = min(floor(dst * (in / out)), in - 1))
+__global__ void __launch_bounds__(256) k_bev_u_update(float* __restrict__ u, const unsigned char* __restrict__ code,
+                                                       const float* __restrict__ tlut, int R, BevGeom g, float ua, float uc) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Nh = g.hh * g.wh, N = g.h * g.w;
+  if (m >= R * N) return;
+  const int img = m / N, n = m - img * N;
+  const int i = n / g.w, j = n - i * g.w;
+  const int si = min(int(floorf(float(i) * (float(g.hh) / float(g.h)))), g.hh - 1);
+  const int sj = min(int(floorf(float(j) * (float(g.wh) / float(g.w)))), g.wh - 1);
+  const int cd = code[size_t(img) * Nh + si * g.wh + sj];
+  float* up = u + size_t(m) * 256 + lane * 4;
+  const f32x4 t = *reinterpret_cast<const f32x4*>(tlut + size_t(cd) * 256 + lane * 4);
+  *reinterpret_cast<f32x4*>(up) = *reinterpret_cast<const f32x4*>(up) * ua + t * uc;
+}
+
 // (a) per head token: prob = sigmoid(logit), accumulate;  (b) per map token (h,w): nearest source in the
 // head grid, threshold -> class ids -> mean embedding -> x0 -> DDIM update.  Two launches of this kernel
 // body are avoided by doing (a) for all head tokens in blocks [0, nbA) and (b) in the rest.
@@ -2156,6 +2218,19 @@ int launch_mean_r(const float* pred, float* out, int B, int r, int N, hipStream_
 int launch_bev_resample(const float* feat, float* out, int R, const BevGeom& g, hipStream_t st) {
   hipLaunchKernelGGL(k_bev_resample, dim3(cdiv(long(R) * g.hh * g.wh, 4)), dim3(256), 0, st, feat, out, R, g);
   return check_launch("k_bev_resample");
+}
+int launch_bev_q(const float* u, const float* rx, float* q_blk, int R, int r, const BevGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL(k_bev_q, dim3(cdiv(long(R) * g.hh * g.wh, 4)), dim3(256), 0, st, u, rx, q_blk, R, r, g);
+  return check_launch("k_bev_q");
+}
+int launch_build_bev_lut(const float* emb, float* lut, int K, float bit_scale, hipStream_t st) {
+  hipLaunchKernelGGL(k_build_bev_lut, dim3(1 << K), dim3(256), 0, st, emb, lut, K, bit_scale);
+  return check_launch("k_build_bev_lut");
+}
+int launch_bev_u_update(float* u, const unsigned char* code, const float* tlut, int R, const BevGeom& g, float ua, float uc,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_bev_u_update, dim3(cdiv(long(R) * g.h * g.w, 4)), dim3(256), 0, st, u, code, tlut, R, g, ua, uc);
+  return check_launch("k_bev_u_update");
 }
 int launch_bev_update(const BevUpdateArgs& a, hipStream_t st) {
   const int nbA = cdiv(long(a.R) * a.g.hh * a.g.wh * a.num_classes, 256);

@@ -23,6 +23,17 @@ int launch_lt(const b3::LayerArgs& la, int grid, hipStream_t st) {
   prof_end(TAG_LAYER_TAIL, st);
   return check_launch("b3::k_layer (last layer + seg tail)");
 }
+// bev (MODE 8) / depth (MODE 9) tails: depth/depth/models/decode_heads/decode_head.py:264-269 (conv_depth);
+// bev/mmdet3d/models/heads/segm/deformable_head_with_time.py:213,235 (conv_seg + sigmoid), fusion_models/ddp.py:290-293 (threshold)
+template <int MODE, bool NT>
+int launch_lt_other(const b3::LayerArgs& la, int grid, hipStream_t st) {
+  static LdsAttrOnce attr;
+  attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_LAYER_TAIL, MODE, 1, NT, false>), int(b3::LYR_LDS_B));
+  prof_begin(TAG_LAYER_TAIL, st);
+  hipLaunchKernelGGL((b3::k_layer<TAG_LAYER_TAIL, MODE, 1, NT, false>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+  prof_end(TAG_LAYER_TAIL, st);
+  return check_launch(MODE == 8 ? "b3::k_layer (last layer + bev tail)" : "b3::k_layer (last layer + depth tail)");
+}
 // teacher forcing (DDP_FLAG_FORCE_X0) is a test instrument: its instantiations exist without the non-temporal variant
 template <int NCH>
 int launch_lt_n(const b3::LayerArgs& la, int grid, hipStream_t st) {
@@ -32,16 +43,14 @@ int launch_lt_n(const b3::LayerArgs& la, int grid, hipStream_t st) {
 }
 }  // namespace
 
-bool b3_layer_tail_supported(int num_classes) {
-  const int nch = (num_classes + 63) / 64;
-  return num_classes >= 1 && (nch == 1 || nch == 3);
-}
+bool b3_layer_tail_supported(int num_classes) { return num_classes >= 1 && num_classes <= 256; }
 
 int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsigned char* stream, const float* bias_ext,
                          const float* seg_bias, hipStream_t st) {
   if (l.M <= 0) return DDP_OK;
-  if (!b3_layer_tail_supported(t.num_classes) || t.mask_sb || l.M != t.M || l.Q != t.Q) {
-    set_error("layer + tail kernel: unsupported call (classes %d, legacy noisy map %d)", t.num_classes, t.mask_sb ? 1 : 0);
+  if (!b3_layer_tail_supported(t.num_classes) || t.mask_sb || l.M != t.M || l.Q != t.Q || t.kind < 0 || t.kind > 2 ||
+      (t.kind != 0 && (t.fuse_next || t.num_classes > 32 || t.x0_force || (t.x0_idx && t.num_classes > 8)))) {
+    set_error("layer + tail kernel: unsupported call (kind %d, classes %d, legacy noisy map %d)", t.kind, t.num_classes, t.mask_sb ? 1 : 0);
     return DDP_E_BADCFG;
   }
 #if DDP_S_F32
@@ -74,6 +83,7 @@ int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsign
   la.num_classes = t.num_classes;
   la.ldl = t.ldl;
   la.prob_mode = t.prob_mode;
+  la.threshold = t.threshold;
   la.alpha = t.alpha;
   la.sigma = t.sigma;
   la.alpha_next = t.alpha_next;
@@ -98,7 +108,15 @@ int launch_b3_layer_tail(const LayerLaunch& l, const TailLaunch& t, const unsign
   const int n_cu = cu_count();
   const int tiles = (l.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  return (t.num_classes + 63) / 64 == 1 ? launch_lt_n<1>(la, grid, st) : launch_lt_n<3>(la, grid, st);
+  const bool nt = l.M >= b3::LYR_NT_MIN_TOKENS;
+  if (t.kind == 1) return nt ? launch_lt_other<8, true>(la, grid, st) : launch_lt_other<8, false>(la, grid, st);
+  if (t.kind == 2) return nt ? launch_lt_other<9, true>(la, grid, st) : launch_lt_other<9, false>(la, grid, st);
+  switch ((t.num_classes + 63) / 64) {
+    case 1: return launch_lt_n<1>(la, grid, st);
+    case 2: return launch_lt_n<2>(la, grid, st);
+    case 3: return launch_lt_n<3>(la, grid, st);
+    default: return launch_lt_n<4>(la, grid, st);
+  }
 }
 
 int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const float* nchw_x, const float* bias, hipStream_t st) {

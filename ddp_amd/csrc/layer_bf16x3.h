@@ -48,6 +48,11 @@
 //      so the layer output never travels to HBM (1 KiB written + 1 KiB read per token and step) and a launch with its
 //      ring prologue / drain goes away.  One concatenated weight stream: 72 layer stages + 2 NCH conv_seg stages + 11
 //      projection stages of layer 0.
+//   8  the LAST decoder layer of a BEV step + that step's tail: conv_seg (<= 32 classes), sigmoid, accumulation of the
+//      probabilities (token-major rows of 32) and - for <= 8 classes - the step's x0 CODE per token: bit k = (sigmoid_k > threshold)
+//      (bev/mmdet3d/models/fusion_models/ddp.py:290-293: the thresholded maps select one of 2^K mean embeddings).
+//   9  the LAST decoder layer of a depth step + the nine per-tap dot products of the 3x3 conv_depth (token-major rows of 32: column
+//      dy*3+dx; k_depth_update sums the neighbours' taps - depth/depth/models/decode_heads/decode_head.py:264-269).
 // Where the cycles of MODE 0 go is measured, not estimated: -DDDP_LYR_STAMP builds + scripts/stamp_layer.py
 // (profiles/r02_layer_cycle_stamps*.json).
 #pragma once
@@ -107,6 +112,7 @@ struct LayerArgs {
   unsigned char* x0_idx;         // optional (DDP_FLAG_RECORD_X0): the step's argmax class per token
   const unsigned char* x0_force; // FORCE instantiations (DDP_FLAG_FORCE_X0): the class fed back INSTEAD of the argmax
   int num_classes, ldl, prob_mode;   // prob_mode: 0 none, 1 prob = softmax, 2 prob += softmax, 3 prob = scores
+  float threshold;               // MODE 8: the bev sampler's threshold on the sigmoid maps (x0_idx = the per-token code, prob = rows of 32)
   float alpha, sigma, alpha_next, sigma_next;
   // MODE 2 (step prologue): Q = S . Wm^T + res[row(m)], then layer 0's value / sampling projections of Q
   const float* res;              // fp32 rows of 256 (the loop-invariant half of the concat-conv, bias included)
@@ -394,6 +400,9 @@ k_layer(LayerArgs la) {
   int j = lane & 31;
   int h = lane >> 5;
   const int M = la.M;
+  constexpr bool LT = MODE == 6 || MODE == 8 || MODE == 9;      // a whole decoder layer followed by a step tail
+  constexpr bool LYR = MODE == 0 || LT;                          // the decoder layer's phases P0 .. LayerNorm1
+  static_assert(!(MODE == 8 || MODE == 9) || NCH == 1, "the bev / depth tails are one 64-row chunk");
   const int ntiles = MODE == 5 ? la.g_tiles : (M + LYR_BM - 1) / LYR_BM;
   if (int(blockIdx.x) >= ntiles) return;
   const unsigned lds0 = (unsigned)(size_t)(lds_float_t*)smem;
@@ -405,7 +414,7 @@ k_layer(LayerArgs la) {
   int fs_tile = blockIdx.x;                                    // MODE 5: the tile whose stages are being fetched
   int n_stages = MODE == 5 ? la.gp[gp_of(int(blockIdx.x))].ns
                        : MODE == 1 ? 2 * NCH : MODE == 4 ? 2 * NCH + LYR_ST_NEXT : MODE == 3 ? LYR_ST_NEXT : MODE == 2 ? LYR_ST_OUT + LYR_ST_NEXT
-                       : MODE == 6 ? LYR_ST_OUT + LYR_ST_FFN + 2 * NCH + (la.has_next ? LYR_ST_NEXT : 0)
+                       : LT ? LYR_ST_OUT + LYR_ST_FFN + 2 * NCH + (la.has_next ? LYR_ST_NEXT : 0)
                        : MODE == 7 ? 2 * LYR_ST_OUT + LYR_ST_NEXT
                                                                                     : (la.has_next ? LYR_STAGES : LYR_ST_OUT + LYR_ST_FFN);
   int sidx = 0;                                                // stage image to fetch next
@@ -551,8 +560,8 @@ k_layer(LayerArgs la) {
       for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
     if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
     if constexpr (MODE == 7) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // the concat-conv's bias
-    if constexpr (MODE == 6) tab[LYR_T_SEG + tid] = la.seg_bias[tid];
-    if constexpr (MODE == 0 || MODE == 6) {
+    if constexpr (LT) tab[LYR_T_SEG + tid] = la.seg_bias[tid];
+    if constexpr (LYR) {
       tab[LYR_T_BO + tid] = la.bo[tid];
       tab[LYR_T_GA0 + tid] = la.ga0[tid];
       tab[LYR_T_BE0 + tid] = la.be0[tid];
@@ -734,7 +743,7 @@ k_layer(LayerArgs la) {
       if (nN > 0) {
         const int mm = mvalid ? m : Mp - 1;
         const int img5 = mm / nN;
-        nchw_off5 = unsigned((img5 * (32 * ns) + 4 * h) * nN + (mm - img5 * nN));
+        nchw_off5 = (unsigned(img5) * unsigned(32 * ns) + unsigned(4 * h)) * unsigned(nN) + unsigned(mm - img5 * nN);   // (< 2^32: host guard)
       }
       auto a_load = [&](int st, f32x4 (&dst)[4]) __attribute__((always_inline)) {
         if (nN > 0) {                                          // (uniform)
@@ -942,12 +951,12 @@ k_layer(LayerArgs la) {
         load_q_fragments(qf);
       }
     }
-    if constexpr (MODE == 0 || MODE == 2 || MODE == 6 || MODE == 7) {
+    if constexpr (LYR || MODE == 2 || MODE == 7) {
     {
     // ---- P0: acc2 = bo + Wo . s  (8 "wide" stages; s fragments fetched one stage ahead); MODE 2: acc2 = Wm . mask
     u32x4 sc[2][3], sn[2][3];
     // MODE 0: the attention output arrives as fp32 fragments (la.Sf): per stage (32 channels = tile t) four quads
-    constexpr bool SF = ((MODE == 0 || MODE == 6) && (DDP_S_F32 != 0)) || MODE == 7;
+    constexpr bool SF = (LYR && (DDP_S_F32 != 0)) || MODE == 7;
     f32x4 sf[4], sh[2];
     const float* sfp = la.Sf + grp * 8192 + lane * 4;
     // MODE 7: this lane's token in the NCHW planes: element offset of (map, channel 4h, token n); stage st (0..7 noise, 8..15 x)
@@ -959,7 +968,7 @@ k_layer(LayerArgs la) {
       int m7 = m_base + j;
       m7 = m7 < M ? m7 : M - 1;
       const int img7 = m7 / ntk7;
-      nchw_off = unsigned((img7 * 256 + 4 * h) * ntk7 + (m7 - img7 * ntk7));
+      nchw_off = (unsigned(img7) * 256u + unsigned(4 * h)) * unsigned(ntk7) + unsigned(m7 - img7 * ntk7);   // (< 2^32: host guard)
     }
     auto sf_fetch = [&](int stn) __attribute__((always_inline)) {          // the fp32 operand fragments of stage stn -> sf[0..3]
       if constexpr (MODE == 7) {
@@ -997,7 +1006,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == 0 || MODE == 6) b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
+        if constexpr (LYR) b = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_BO + t * 32 + 8 * g + 4 * ht);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2[t][4 * g + e] = b[e];
       }
@@ -1189,7 +1198,7 @@ k_layer(LayerArgs la) {
         }
       }
     }
-    if constexpr (MODE == 0 || MODE == 6) {
+    if constexpr (LYR) {
     // residual fragments: fetched under the last two stages
     // (fp32: 32 x 16 B per lane instead of 48 - the r02i stamps put most of P0's idle time on these two fetches: every CU
     // asks for its residual rows in the same microseconds)
@@ -1407,7 +1416,7 @@ k_layer(LayerArgs la) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] = acc2[t][8 * gp + e];
           split8_packed(xv, xa[b][0], xa[b][1], xa[b][2]);
-          if constexpr (MODE != 6) {                  // (MODE 6: the layer output stays in xa - conv_seg's operand, the tail below)
+          if constexpr (!LT) {                        // (MODE 6 / 8 / 9: the layer output stays in xa - the tail's operand, below)
             store_q_block(qst, b, xv);
             if (la.Q_sb) {
 #pragma unroll
@@ -1421,6 +1430,41 @@ k_layer(LayerArgs la) {
     DDP_LYR_STAMP_AT(5)                                        // LayerNorm1 + FiLM + split + q' stores
     }   // MODE 0 / 6
     }   // MODE 0 / 2 / 6 only
+    }
+    if constexpr (MODE == 8 || MODE == 9) {
+      // ---- bev / depth tail: ONE 64-row chunk of the head convolution on the layer output LayerNorm1 left in xa.  This lane holds
+      // rows 8g + 4h + e of tile t = 0 (the head has <= 32 rows: tile 1 is zero weights)
+      refresh();
+      f32x16 lg[2];
+      bias_init(lg, LYR_T_SEG / 64);
+      tall_pair(lg[0], lg[1], I1);
+      const int m = m_base + j;
+      const bool valid = m < M;
+      float* pr = la.prob + size_t(valid ? m : 0) * 32 + 4 * h;            // token-major rows of 32 floats
+      if constexpr (MODE == 8) {
+        const int K = la.num_classes;
+        unsigned code = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (8 * g >= K) break;                                            // (uniform)
+          f32x4 p;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p[e] = 1.0f / (1.0f + expf(-lg[0][4 * g + e]));                  // torch.sigmoid (heads/segm/deformable_head_with_time.py:235)
+            if (g == 0 && 4 * h + e < K && p[e] > la.threshold) code |= 1u << (4 * h + e);
+          }
+          if (la.prob_mode == 2) p += *reinterpret_cast<const f32x4*>(pr + 8 * g);
+          if (valid) *reinterpret_cast<f32x4*>(pr + 8 * g) = p;             // (columns >= K: never read)
+        }
+        code |= unsigned(__shfl_xor(int(code), 32, 64));
+        if (la.x0_idx && valid && h == 0) la.x0_idx[m] = (unsigned char)code;
+      } else {
+        if (valid) {
+          *reinterpret_cast<f32x4*>(pr) = f32x4{lg[0][0], lg[0][1], lg[0][2], lg[0][3]};                      // taps 4h .. 4h + 3
+          if (h == 0) *reinterpret_cast<f32x4*>(pr + 8) = f32x4{lg[0][4], lg[0][5], lg[0][6], lg[0][7]};      // taps 8 .. 11 (8 is the last)
+        }
+      }
+      continue;
     }
     if constexpr (MODE == 1 || MODE == 4 || MODE == 6) {
       // ---- seg tail: q fragments of this tile (the layer output; MODE 6: LayerNorm1 just left them in xa), scores = conv_seg(q),
@@ -1629,7 +1673,7 @@ k_layer(LayerArgs la) {
       }
       }   // la.mask_sb
     }
-    if constexpr (MODE != 1) {
+    if constexpr (MODE != 1 && MODE != 8 && MODE != 9) {
     refresh();
     // ---- P3: the next layer's value_proj (4 chunks of 64 channels) and sampling projection (2 chunks)
     if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || la.has_next) {       // (MODE 6 without a next step left the tile above)

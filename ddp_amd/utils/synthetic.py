@@ -62,6 +62,8 @@ def _offset_ring_bias():
 PROFILES = {
     'init': dict(off_w=0.02, off_b=0.3, attn_w=0.05, attn_b=1.0, seg_gain=1.0),
     'trained_like': dict(off_w=0.15, off_b=1.0, attn_w=0.3, attn_b=2.0, seg_gain=8.0),
+    # content-dependent offsets of +- 6 px: every 8-token group of the LDS-staged gather has taps outside its window
+    'wide_offsets': dict(off_w=0.375, off_b=1.5, attn_w=0.3, attn_b=2.0, seg_gain=8.0),
 }
 
 

@@ -69,7 +69,7 @@ enum { DDP_GEMM_F32_MFMA = 0, DDP_GEMM_BF16X3 = 1 };
  * buffer, filled before ddp_sample) instead of its own argmax (ddp.py:235); scores, softmax accumulation, update and
  * everything else are unchanged, and the step's OWN argmax is still recorded next to the supplied one.  With the
  * decisions of a reference run supplied, the loop has no discontinuity left and the outputs must agree with that run to
- * rounding (tests/test_fullsize_reference.py).  Separate kernel instantiations: the product's tails are not touched. */
+ * rounding (tests/test_full_size_parity.py).  Separate kernel instantiations: the product's tails are not touched. */
 enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECORD_X0 = 4, DDP_FLAG_GATHER_GUESS_ZERO = 8,
        DDP_FLAG_FCN_PREPARED = 16 /* ddp_sample_fcn: the workspace holds what ddp_prepare_fcn wrote */,
        DDP_FLAG_FORCE_X0 = 32,
@@ -183,7 +183,12 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
  * rounding" and "decisions differ only where the reference's own top-2 gap is at rounding level"
  * (tests/test_full_size_parity.py).
  * With DDP_FLAG_FORCE_X0 the buffer is (2, K, B*r*h*w): [0] = the decisions to feed back, written by the caller BEFORE
- * ddp_sample (values < num_classes); [1] = the argmax the engine itself found at every step under that forcing. */
+ * ddp_sample (values < num_classes); [1] = the argmax the engine itself found at every step under that forcing.  The library
+ * cannot tell whether [0] was filled: a caller that sets DDP_FLAG_FORCE_X0 and does not write it feeds back whatever the
+ * workspace held (values >= num_classes are read as class 0) - ddp_amd.engine.DDPEngine refuses to sample until
+ * set_x0_decisions() ran.  Both flags are rejected (DDP_E_BADCFG) for tasks other than DDP_TASK_SEG.
+ * The workspace LAYOUT (which bytes hold what, incl. this buffer's place) is an implementation detail of one build: it is
+ * queried, never assumed, and may change between library builds of the same DDP_ABI_VERSION. */
 int ddp_x0_trace(const ddp_cfg* cfg, void* d_workspace, const unsigned char** d_idx);
 
 /* ---- finer-grained entry points (unit tests, and the decode_head plugin surface) ------------- */
@@ -274,7 +279,7 @@ int ddp_seg_aug_postprocess(const ddp_seg_aug* augs, int n_aug, int batch, int n
  * what the reference does with full-size tensors: resize each covering window's scores to the window size, sum them in window
  * order (row-major), divide by the number of covering windows, crop to (keep_h, keep_w) = img_shape, resize to (out_h, out_w) =
  * ori_shape, [softmax,] undo the flip, argmax.  Neither the per-window (B,K,crop_h,crop_w) logits nor `preds` / `count_mat` at
- * image size exist.  A pixel may be covered by at most 3 window rows and 3 window columns (stride >= crop / 3).
+ * image size exist.  A pixel may be covered by at most 4 window rows and 4 window columns (stride >= crop / 4).
  * d_scores[i * n_cols + j] (B,K,h,w); d_seg (B,out_h,out_w) uint8 or NULL; d_prob optional (B,K,out_h,out_w):
  * prob_mode 1 = softmax probabilities (`inference`), 2 = the averaged scores themselves (`slide_inference`'s return value). */
 #define DDP_MAX_WINDOWS 64

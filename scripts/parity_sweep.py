@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     if args.config == 'c3_trained':     # the trained-like weight profile at the Cityscapes map size against fp64 (until round 4 part of
         torch.set_num_threads(T._usable_cores())      # the suite as test_c3_size_trained_like_weights: ~3 CPU-minutes of oracle)
-        T.c3_size_trained_like_weights(torch.device('cuda:0'))
+        T.test_c3_size_trained_like_weights(torch.device('cuda:0'))
         print('c3_trained: assertions hold')
         return
     B, h, w, K, ncls, L, acc, variants, wseed, iseed = CONFIGS[args.config]

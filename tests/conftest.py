@@ -8,8 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption('--run-slow', action='store_true', default=False, help='also run the tests marked slow (minutes of CPU oracle each)')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: minutes of CPU oracle per test; skipped unless --run-slow is given')
 
 
 def _has_gpu():
@@ -21,6 +26,11 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if not config.getoption('--run-slow'):
+        skip_slow = pytest.mark.skip(reason='slow: pass --run-slow')
+        for item in items:
+            if 'slow' in item.keywords:
+                item.add_marker(skip_slow)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason='no GPU visible')

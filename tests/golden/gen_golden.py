@@ -61,6 +61,13 @@ SEG_CASES = [
          accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=6, trace=False, time_difference=0),
     dict(name='seg_td2', h=8, w=11, num_classes=150, timesteps=4, randsteps=2, bit_scale=0.01,
          accumulation=False, noise_schedule='cosine', diffusion='ddim', seed=7, trace=False, time_difference=2),
+    # content-dependent weight profiles (ddp_amd/utils/synthetic.py PROFILES; VERDICT r05 "next" #4): sampling offsets that react
+    # to the query by +- 2.4 px ('trained_like') and by +- 6 px ('wide_offsets': every tap group leaves the gather's staged
+    # window), peaked attention, 8x class scores - on a small map
+    dict(name='seg_trained_small', h=24, w=40, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=8, trace=False, profile='trained_like'),
+    dict(name='seg_wide_offsets', h=24, w=40, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01,
+         accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=9, trace=False, profile='wide_offsets'),
 ]
 
 DEPTH_CASES = [
@@ -95,6 +102,9 @@ BEV_CASES = [
          num_layers=5, seed=23, input_scope=[[-51.2, 51.2, 7.314285714285714], [-51.2, 51.2, 10.24]],
          output_scope=[[-50, 50, 4.0], [-50, 50, 6.25]]),
 ]
+
+
+ONLY = set()
 
 
 def fingerprint(t):
@@ -161,6 +171,8 @@ def gen_seg():
     build_segmentor, Config, revert = ref_shim.import_seg()
     cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
     for case in SEG_CASES:
+        if ONLY and case['name'] not in ONLY:
+            continue
         cfg = Config.fromfile(cfg_path)
         m = cfg.model
         m.backbone.init_cfg = None
@@ -178,7 +190,7 @@ def gen_seg():
         m.decode_head.num_classes = case['num_classes']
         m.auxiliary_head.num_classes = case['num_classes']
         model = revert(build_segmentor(m)).eval()
-        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['seed'] + 100)
+        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['seed'] + 100, profile=case.get('profile', 'init'))
         load_hot_path(model, sd)
         x, noise = synthetic.make_inputs(1, case['h'], case['w'], case['randsteps'], 256, 256, seed=case['seed'])
         step_noise = None
@@ -729,6 +741,12 @@ FULLSIZE_SEG = [
     dict(name='full_c1', B=1, b=0, h=128, w=128, num_classes=150, timesteps=1, accumulation=True, sd_seed=2, in_seed=10, stride=11),
     dict(name='full_c2', B=8, b=0, h=128, w=256, num_classes=150, timesteps=3, accumulation=True, sd_seed=2, in_seed=0, stride=11),
     dict(name='full_c3', B=4, b=2, h=256, w=512, num_classes=19, timesteps=10, accumulation=False, sd_seed=3, in_seed=30, stride=7),
+    # round 6: a SECOND image of the C2 and C3 batches, and the content-dependent 'trained_like' weight
+    # profile at C2 size (the seeds of tests/test_full_size_parity.py::test_c2_size_trained_like_weights, image 1 of its 2-image draw)
+    dict(name='full_c2_b5', B=8, b=5, h=128, w=256, num_classes=150, timesteps=3, accumulation=True, sd_seed=2, in_seed=0, stride=11),
+    dict(name='full_c3_b0', B=4, b=0, h=256, w=512, num_classes=19, timesteps=10, accumulation=False, sd_seed=3, in_seed=30, stride=7),
+    dict(name='full_c2_trained', B=2, b=1, h=128, w=256, num_classes=150, timesteps=3, accumulation=True, sd_seed=7, in_seed=4, stride=11,
+         profile='trained_like'),
 ]
 FULLSIZE_DEPTH = [
     dict(name='full_c4', B=16, b=0, h=88, w=304, timesteps=20, sd_seed=4, in_seed=40, bit_scale=0.1, min_depth=1e-3, max_depth=80.0),
@@ -749,6 +767,8 @@ def gen_fullsize_seg():
     build_segmentor, Config, revert = ref_shim.import_seg()
     cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
     for case in FULLSIZE_SEG:
+        if ONLY and case['name'] not in ONLY:
+            continue
         cfg = Config.fromfile(cfg_path)
         m = cfg.model
         m.backbone.init_cfg = None
@@ -757,7 +777,7 @@ def gen_fullsize_seg():
         m.decode_head.num_classes = case['num_classes']
         m.auxiliary_head.num_classes = case['num_classes']
         model = revert(build_segmentor(m)).eval()
-        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['sd_seed'])
+        sd = synthetic.make_state_dict('seg', case['num_classes'], 6, 256, seed=case['sd_seed'], profile=case.get('profile', 'init'))
         load_hot_path(model, sd)
         xb, nb = synthetic.make_inputs(case['B'], case['h'], case['w'], 1, 256, 256, seed=case['in_seed'])
         b = case['b']
@@ -857,7 +877,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--task', choices=['seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide', 'fullsize',
                                       'fullsize_seg', 'fullsize_depth', 'fullsize_bev', 'all'], default='all')
+    ap.add_argument('--only', default='', help='comma-separated fixture names: regenerate just these (seg / fullsize_seg tasks)')
     args = ap.parse_args()
+    global ONLY
+    ONLY = set(n for n in args.only.split(',') if n)
     torch.set_num_threads(8)
     if args.task == 'all':
         for t in ('seg', 'depth', 'bev', 'post', 'neck', 'fcn', 'fpn', 'aligned', 'loopfcn', 'aug', 'dpost', 'slide'):       # separate processes: the trees' registries collide

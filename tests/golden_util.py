@@ -34,7 +34,7 @@ def load_case(name):
     nl = cfg.get('num_layers', 6)
     cx = cfg.get('feat_channels', 256)
     ncls = cfg.get('num_classes', 6 if task == 'bev' else 1)
-    sd = synthetic.make_state_dict(task, ncls, nl, cx, seed=cfg['seed'] + 100)
+    sd = synthetic.make_state_dict(task, ncls, nl, cx, seed=cfg['seed'] + 100, profile=cfg.get('profile', 'init'))
     cm = 1 if task == 'depth' else 256
     x, noise = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], cx, cm, seed=cfg['seed'])
     # the seeded generators must reproduce exactly what the reference was fed
@@ -66,7 +66,8 @@ def load_fullsize_case(name):
     arrays = {k: torch.from_numpy(z[k]) for k in z.files if k != 'config'}
     task = FULLSIZE_TASKS[cfg['task']]
     cx = cfg.get('feat_channels', 256)
-    sd = synthetic.make_state_dict(task, cfg.get('num_classes', 6 if task == 'bev' else 1), cfg.get('num_layers', 6), cx, seed=cfg['sd_seed'])
+    sd = synthetic.make_state_dict(task, cfg.get('num_classes', 6 if task == 'bev' else 1), cfg.get('num_layers', 6), cx, seed=cfg['sd_seed'],
+                                 profile=cfg.get('profile', 'init'))
     x, noise = synthetic.make_inputs(cfg['B'], cfg['h'], cfg['w'], cfg.get('randsteps', 1), cx, 1 if task == 'depth' else 256, seed=cfg['in_seed'])
     b = cfg['b']
     assert abs(synthetic.checksum(sd) - float(arrays['weights_fp'])) <= 1e-9 * abs(float(arrays['weights_fp']))

@@ -446,8 +446,10 @@ def test_c2_size_trained_like_weights(dev):
     assert dg <= 4 * dc + 1e-5 and agree >= agree_c - 2e-3
 
 
-def c3_size_trained_like_weights(dev):
-    """NOT collected (scripts/parity_sweep.py --config c3_trained runs it: two C3-size oracle runs, one in fp64, ~3 CPU-minutes).
+@pytest.mark.slow
+def test_c3_size_trained_like_weights(dev):
+    """Marked ``slow`` (two C3-size oracle runs, one in fp64, ~3 CPU-minutes): skipped unless --run-slow is given (tests/conftest.py)
+    (GPUTEST's time budget), run with ``pytest -m gpu --run-slow -k c3_size`` or scripts/parity_sweep.py --config c3_trained.
     The trained-like weight profile (see test_c2_size_trained_like_weights) at the Cityscapes map size: one image of
     256 x 512 tokens, 19 classes, 3 steps of argmax feedback (the spatial size is what this adds: 4x the tiles, windows of
     a 512-wide map; the 10-step accumulation of rounding is test_c3's subject).  Same fp32-class bar against fp64."""

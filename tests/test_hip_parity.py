@@ -1,10 +1,14 @@
 """Parity of the HIP path (through the C ABI of libddp_mi355x.so) against the CPU oracle and the
 golden vectors generated from the reference.  Needs an MI355X: ``pytest -m gpu``.
 
-Tolerances: the reference is fp32; the HIP path computes in fp32 (f32 MFMA, exact products, other
-summation order).  north_star bar: final logits / depth within 1e-3 relative (max|a-b| / max|b|);
-measured here ~1e-5, asserted at 2e-4 to leave room for libm differences, with argmax agreement
-reported for the classification outputs.
+Tolerances: the reference is fp32; the HIP path computes fp32-class results - by default on the bf16 matrix cores with
+every fp32 operand split exactly into three bf16 pieces and the six significant cross products accumulated in fp32
+(``gemm='bf16x3'``, csrc/gemm_bf16x3.h; tests/test_b3_arithmetic.py bounds it against fp64), or with exact products on
+the f32-input MFMA (``gemm='f32'``); both in another summation order than the reference.  north_star bar: final logits /
+depth within 1e-3 relative (max|a-b| / max|b|); measured here ~1e-5, asserted at 2e-4 to leave room for libm
+differences, with argmax agreement reported for the classification outputs.  The two fixtures made with
+content-dependent weight profiles (``seg_trained_small``, ``seg_wide_offsets``: the network itself amplifies rounding,
+see tests/test_full_size_parity.py::test_c2_size_trained_like_weights) are asserted at the north_star gate.
 """
 import ctypes as C
 
@@ -262,13 +266,14 @@ def test_sample_golden(dev, name, variant):
     ref = g['out']
     assert out.shape == ref.shape
     err = max_rel(out.cpu(), ref)
+    amplifying = cfg.get('profile', 'init') != 'init'      # content-dependent sampling offsets: rounding is amplified by the network
     if cfg['task'] != 'depth':
         agree = (out.cpu().argmax(1) == ref.argmax(1)).float().mean().item()
         print(f'{name}: max-rel {err:.3e}, argmax agreement {agree:.4f}')
-        assert agree > 0.999
+        assert agree > (0.995 if amplifying else 0.999)
     else:
         print(f'{name}: max-rel {err:.3e}')
-    assert err < REL < GATE
+    assert err < (GATE if amplifying else REL) <= GATE
 
 
 @pytest.mark.parametrize('name', ['seg_ade_k3', 'seg_city_k10', 'seg_td2'])
@@ -281,6 +286,46 @@ def test_fused_and_unfused_tail_same_bits(dev, name):
     a = _engine(cfg, sd, dev, fused_tail=True).sample(dx, dn).clone()
     b = _engine(cfg, sd, dev, fused_tail=False).sample(dx, dn)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('r', [1, 2])
+@pytest.mark.parametrize('ncls', [19, 64, 65, 100, 128, 150, 192, 193, 256])
+def test_fused_and_unfused_tail_same_bits_class_counts(dev, ncls, r):
+    """VERDICT r05 "next" #2: k_layer MODE 6 exists for every class count 1..256 (1, 2, 3, 4 chunks of 64 classes) and for r > 1
+    (res_rn: r noisy maps share one x projection) - no segmentation configuration falls back to the three-kernel tail silently.
+    Fused == unfused bit for bit on seeded inputs (segmentors/ddp.py:219-245), odd map size, K = 3, accumulation."""
+    from ddp_amd.utils import synthetic
+    sd = synthetic.make_state_dict('seg', ncls, 6, 256, seed=300 + ncls)
+    h, w = 11, 19
+    x, noise = synthetic.make_inputs(2, h, w, r, 256, 256, seed=ncls + r)
+    cfg = dict(task='seg', h=h, w=w, randsteps=r, timesteps=3, bit_scale=0.01, num_classes=ncls, accumulation=True,
+               noise_schedule='cosine', diffusion='ddim')
+    dx, dn = x.to(dev), noise.to(dev)
+    a = _engine(cfg, sd, dev, batch=2, fused_tail=True).sample(dx, dn).clone()
+    b = _engine(cfg, sd, dev, batch=2, fused_tail=False).sample(dx, dn)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.allclose(a.sum(1), torch.ones_like(a.sum(1)), atol=1e-5)
+
+
+@pytest.mark.parametrize('name', case_names('depth') + case_names('bev'))
+def test_fused_and_unfused_step_boundary_depth_bev(dev, name):
+    """Round 6: the depth and BEV step boundaries fused the way MODE 6 / 7 fused the segmentation sampler's - the last layer of a
+    step carries the head convolution as its tail (k_layer MODE 9: the nine taps of conv_depth; MODE 8: conv_seg + sigmoid +
+    accumulation + the thresholded x0 code), and the BEV sampler runs the u chain (loop-invariant resample(W_x x + b), u = W_m m
+    updated through the 2^K-row table).  Against DDP_FLAG_UNFUSED_TAIL = the round-5 launches (head GEMM on the SB layer output,
+    k_depth_update / k_bev_update on the 256-channel map).  Not bit-identical: the head contraction runs in the layer kernel's
+    K order instead of the tile GEMM's, and resample(a + b) != resample(a) + resample(b) in fp32 - asserted at rounding level,
+    both against each other and (test_sample_golden) against the reference fixture.
+    depth/depth/models/depther/ddp.py:229-247; bev/mmdet3d/models/fusion_models/ddp.py:268-301."""
+    cfg, sd, x, noise, _, g = load_case(name)
+    dx, dn = x.to(dev), noise.unsqueeze(0).contiguous().to(dev)
+    a = _engine(cfg, sd, dev, fused_tail=True).sample(dx, dn).clone().cpu()
+    b = _engine(cfg, sd, dev, fused_tail=False).sample(dx, dn).cpu()
+    err = max_rel(a, b)
+    print(f'{name}: fused vs unfused step boundary max-rel {err:.3e}; vs reference fused {max_rel(a, g["out"]):.3e} unfused {max_rel(b, g["out"]):.3e}')
+    assert err < 5e-5
+    if cfg['task'] == 'bev':
+        assert float(((a > 0.5) == (b > 0.5)).float().mean()) > 0.9995
 
 
 def test_sample_batch_matches_per_image_oracle(dev):

@@ -205,7 +205,7 @@ def test_sampler_loop_around_fcn_head_golden(name):
     assert max_rel(out, g['out']) < TOL
 
 
-@pytest.mark.parametrize('name', ['full_c1', 'full_c2'])
+@pytest.mark.parametrize('name', ['full_c1', 'full_c2', 'full_c2_b5', 'full_c2_trained'])
 def test_oracle_matches_reference_at_full_size(name):
     """The full-size fixtures (gen_golden.py --task fullsize: the reference at BASELINE.json's sizes) pin the oracle where the bench
     is quoted, not only on <= 33-px maps: C1 (1x512x512, K = 1) and one C2 image (512x1024, K = 3, 150 classes) - same per-step
