@@ -166,26 +166,31 @@ def gather_rank_stats(elapsed, step_ms, images_per_rank_step, steps, dev):
     return per_rank, float(t.item())
 
 
-def _gpu_numa_nodes(world):
-    """NUMA node of every visible GPU (sysfs), and the cores of every node; (None, None) when the box does not say."""
+def _gpu_numa_nodes(world, sysfs_root='', bdfs=None):
+    """NUMA node of every visible GPU (sysfs), and the cores of every node; (None, None) when the box does not say.
+    ``sysfs_root`` / ``bdfs``: read another tree / take the GPUs' PCI addresses from a list instead of the HIP runtime - how
+    ``--dry-run-world`` and tests/test_host_logic.py walk this code against a fake 8-GPU node."""
     try:
         nodes = []
         for i in range(world):
-            p = torch.cuda.get_device_properties(i)
-            bus = getattr(p, 'pci_bus_id', None)
-            if bus is None:
-                return None, None
-            if isinstance(bus, str):                      # 'dddd:bb:dd.f'
-                bdf = bus.lower()
-            else:                                         # torch reports domain / bus / device as integers
-                bdf = f'{int(getattr(p, "pci_domain_id", 0)):04x}:{int(bus):02x}:{int(getattr(p, "pci_device_id", 0)):02x}.0'
-            nodes.append(int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read()))
+            if bdfs is not None:
+                bdf = bdfs[i].strip().lower()
+            else:
+                p = torch.cuda.get_device_properties(i)
+                bus = getattr(p, 'pci_bus_id', None)
+                if bus is None:
+                    return None, None
+                if isinstance(bus, str):                      # 'dddd:bb:dd.f'
+                    bdf = bus.lower()
+                else:                                         # torch reports domain / bus / device as integers
+                    bdf = f'{int(getattr(p, "pci_domain_id", 0)):04x}:{int(bus):02x}:{int(getattr(p, "pci_device_id", 0)):02x}.0'
+            nodes.append(int(open(f'{sysfs_root}/sys/bus/pci/devices/{bdf}/numa_node').read()))
         cpus = {}
         for n in set(nodes):
             if n < 0:
                 return None, None
             ids = []
-            for part in open(f'/sys/devices/system/node/node{n}/cpulist').read().strip().split(','):
+            for part in open(f'{sysfs_root}/sys/devices/system/node/node{n}/cpulist').read().strip().split(','):
                 a, _, b = part.partition('-')
                 ids += list(range(int(a), int(b or a) + 1))
             cpus[n] = ids
@@ -194,7 +199,7 @@ def _gpu_numa_nodes(world):
         return None, None
 
 
-def pin_rank(local_rank, world):
+def pin_rank(local_rank, world, sysfs_root='', bdfs=None):
     """apply plan_affinity to this process; -> what was done (for the JSON line).  Never fatal."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
@@ -205,7 +210,7 @@ def pin_rank(local_rank, world):
                 quota = max(1, int(int(q) / int(p)))
         except Exception:
             pass
-        nodes, cpus = _gpu_numa_nodes(world)
+        nodes, cpus = _gpu_numa_nodes(world, sysfs_root, bdfs)
         mine = plan_affinity(allowed, world, local_rank, quota, nodes, cpus)
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, len(mine)))
@@ -221,11 +226,12 @@ def require_devices(n):
         raise SystemExit(f'bench.py: {n} device(s) required, {have} visible (one rank per GPU; there is no CPU path)')
 
 
-def relaunch_distributed(n):
+def relaunch_distributed(n, check_devices=True):
     """`python bench.py --gpus N` (N > 1) without a rendezvous environment: re-exec under torch.distributed.run."""
     import socket
     import subprocess
-    require_devices(n)
+    if check_devices:
+        require_devices(n)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -614,6 +620,37 @@ def size_stream(n_sizes, sd, wl, dev):
                     'split planes, weight streams and LUTs are kept)'}
 
 
+class _DryEngine:
+    """--dry-run-world: stands where DDPEngine stands so that the N-rank CONTROL FLOW of this file (relaunch under the launcher,
+    process group, weight broadcast + replica check, pinning, barriers, per-rank statistics, the line's schema) can be walked on a
+    box without GPUs.  It computes nothing - a dry run's line carries ``value: null`` and ``dry_run: true``."""
+    gemm, fused_layer = 'bf16x3', True
+
+    def __init__(self, wl, batch, call_s=0.002):
+        self.shape = (batch, 1 if wl['task'] == 'depth' else wl['num_classes'], wl['h'], wl['w'])
+        self.call_s = call_s
+
+    def out_shape(self):
+        return self.shape
+
+    def prepare(self):
+        pass
+
+    def sample(self, x, noise, out=None):
+        time.sleep(self.call_s)
+        return out
+
+
+class _HostMark:
+    """torch.cuda.Event's two methods on the host clock (dry run)"""
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -647,12 +684,20 @@ def main():
     ap.add_argument('--next-rows', action='store_true',
                     help='also time the rows either side of the loop on the same batch (SURVEY.md §8 f1/f2): FPN + '
                          'MultiStageMerging neck, fused post-loop epilogue; reported under "next_rows", never part of value')
+    ap.add_argument('--dry-run-world', type=int, default=0, metavar='N',
+                    help='rehearse the N-rank control flow WITHOUT GPUs (CPU tensors, gloo): relaunch under torch.distributed.run, '
+                         'weight broadcast + replica check, pinning plan (DDP_BENCH_FAKE_SYSFS = root of a fake sysfs tree with a '
+                         'gpus.txt of PCI addresses), barriers, per-rank statistics, one JSON line with "dry_run": true and '
+                         '"value": null.  No kernel runs; nothing in the line is a measurement')
     args = ap.parse_args()
+    dry = args.dry_run_world > 0
+    if dry:
+        args.gpus = args.dry_run_world
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher (the reference's tools/dist_test.sh:10-20 does the same with
         # torch.distributed.launch --nproc_per_node=$GPUS): one rank per GPU over RCCL, rank 0 prints the JSON line
-        sys.exit(relaunch_distributed(args.gpus))
+        sys.exit(relaunch_distributed(args.gpus, check_devices=not dry))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -665,19 +710,36 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} '
                          f'(or run `python bench.py --gpus {args.gpus}` without a rendezvous environment)')
-    require_devices(world)
+    if not dry:
+        require_devices(world)
     dist_on = world > 1 or args.force_dist
     # N > 1: every rank (and the loader workers / intra-op threads it spawns) on its own cores, near its GPU when the box says
     # (the split is over the ranks of THIS node: LOCAL_WORLD_SIZE under torchrun, never more than the visible devices)
-    local_world = max(1, min(int(os.environ.get('LOCAL_WORLD_SIZE', world)), world, torch.cuda.device_count() or world))
-    pinned = pin_rank(local_rank, local_world) if (world > 1 and not args.no_pin) else None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    local_world = max(1, min(int(os.environ.get('LOCAL_WORLD_SIZE', world)), world, (torch.cuda.device_count() or world) if not dry else world))
+    fake_sysfs, fake_bdfs = '', None
+    if dry and os.environ.get('DDP_BENCH_FAKE_SYSFS'):
+        fake_sysfs = os.environ['DDP_BENCH_FAKE_SYSFS']
+        fake_bdfs = open(os.path.join(fake_sysfs, 'gpus.txt')).read().split()
+    pinned = pin_rank(local_rank, local_world, fake_sysfs, fake_bdfs) if (world > 1 and not args.no_pin) else None
+    if dry:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    n_ranks_counted = 1
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # how many ranks the group REALLY has: every rank contributes a 1 to a device all_reduce (never the --gpus flag, never
+        # the environment) - the line's rccl_ranks
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        n_ranks_counted = int(ones.item())
 
     wl = WORKLOADS[args.workload]
     B, h, w, K = wl['batch'], wl['h'], wl['w'], wl['timesteps']
@@ -706,17 +768,21 @@ def main():
               bit_scale=wl['bit_scale'], accumulation=wl['accumulation'], feat_channels=cx, device=dev, weights=weights)
     if task == 'bev':
         kw.update(bev_input_scope=wl['bev_input_scope'], bev_output_scope=wl['bev_output_scope'])
-    eng = DDPEngine(sd, task, **kw)
+    eng = _DryEngine(wl, B) if dry else DDPEngine(sd, task, **kw)
     # synthetic inputs, distinct per rank (independent images), resident in HBM before timing
-    x, noise = synthetic.make_inputs(B, h, w, wl['randsteps'], cx, cm, seed=1000 * rank)
-    dx, dn = x.to(dev), noise.to(dev)
-    out = torch.empty(eng.out_shape(), dtype=torch.float32, device=dev)
+    if dry:                                     # (the stub never reads them: no 268-MB draws per rank on a CPU box)
+        x = noise = dx = dn = torch.zeros(1)
+    else:
+        x, noise = synthetic.make_inputs(B, h, w, wl['randsteps'], cx, cm, seed=1000 * rank)
+        dx, dn = x.to(dev), noise.to(dev)
+    out = torch.empty(eng.out_shape() if not dry else (1,), dtype=torch.float32, device=dev)
     eng.prepare()
+    device_sync = (lambda: None) if dry else torch.cuda.synchronize
 
     def barrier():
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def one_step():
         for _ in range(calls_per_step):
@@ -727,7 +793,7 @@ def main():
     # per-step spread (segmentation/tools/benchmark.py:80-109 reports the rate over many iterations; SURVEY §8d asks for mean and
     # variance): one HIP event per step on the stream the library launches on - an event record is stream-ordered and costs no
     # synchronisation; the contract's clock stays the barrier-to-barrier wall time around all K steps
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [_HostMark() if dry else torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
@@ -742,9 +808,15 @@ def main():
         per_rank, elapsed = gather_rank_stats(elapsed, step_ms, B * calls_per_step, args.steps, dev)
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = B * calls_per_step * world * args.steps / elapsed
+    if dry and per_rank is not None:
+        per_rank['images_per_s'] = None          # (clocks of a stub: the ranks' elapsed / step times stay, as plumbing evidence)
 
     # ---- power leg (rank 0): the same loop back to back for a couple of seconds with package power and shader clock
     # sampled beside it; also gives the SUSTAINED rate (the timed region above is a fraction of a second)
+    if dry:                                      # nothing below measures anything without a GPU
+        args.no_power = args.no_roofline = args.no_trained_like = args.no_cpu_baseline = True
+        args.next_rows = args.host_leg = False
+        args.size_stream = 0
     power = None
     if rank == 0 and not args.no_power:
         ps = PowerSampler(local_rank)
@@ -775,7 +847,7 @@ def main():
     # ---- roofline leg: HIP events around every launch of the dominant kernel, same workload ----------
     roofline = None
     hh, wh = eng.out_shape()[-2:]
-    M = B * wl['randsteps'] * hh * wh               # tokens on the decoder grid
+    M = B * wl['randsteps'] * hh * wh               # tokens on the decoder grid (unused by a dry run)
     if not args.no_roofline:
         lib = _lib.load()
         _lib.check(lib.ddp_profile_begin(TAG_FC2_LN))
@@ -1041,24 +1113,27 @@ def main():
 
     # what the process group itself says (never the --gpus flag): 1 without a group
     n_ranks = dist.get_world_size() if dist_on else 1
-    assert n_ranks == world
+    assert n_ranks == world == n_ranks_counted, (n_ranks, world, n_ranks_counted)
     if rank == 0:
         line = {
             'metric': 'images/s at K DDIM steps (512x1024, 150-class) per GPU and whole node' if args.workload == 'ade_swin_t_k3_8x512x1024'
                       else f'images/s at {K} DDIM steps ({args.workload})',
-            'value': round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': n_ranks, 'steps': args.steps,
+            'value': None if dry else round(images_per_s, 3), 'unit': 'images/s', 'n_gpus': n_ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32 (bf16x3-split MFMA products, fp32 accumulate)' if eng.gemm == 'bf16x3' else 'f32',
-            'data': 'synthetic',
+            'data': 'synthetic' if not dry else 'none (--dry-run-world: control-flow rehearsal on CPU / gloo, no kernel ran)',
+            'dry_run': dry,
             'config': {'workload': args.workload + (' (ADE20K Swin-T DDP decode head, 3-step DDIM, batch 8x512x1024 '
                                                     'per GPU; x (8,256,128,256), random-init weights)'
                                                     if args.workload == 'ade_swin_t_k3_8x512x1024' else
                                                     f' ({task} decoder, batch {B} per GPU, x ({B},{cx},{h},{w}), random-init weights)'),
                        'images_per_gpu_per_step': B * calls_per_step, 'images_per_call': B, 'ddim_steps': K, 'tokens_per_image': h * w,
                        'parallelism': f'dp{world} (independent images, weights broadcast once)', 'gemm_engine': eng.gemm},
-            'rccl_ranks': n_ranks if dist_on else 0, 'process_group': (dist.get_backend() if dist_on else None),
-            'images_per_s_per_gpu': round(images_per_s / world, 3), 'per_rank': per_rank, 'affinity': pinned,
+            # ranks counted by an all_reduce of ones through the group itself (0: no process group)
+            'rccl_ranks': n_ranks_counted if (dist_on and not dry) else 0, 'group_ranks': n_ranks_counted if dist_on else 0,
+            'process_group': (dist.get_backend() if dist_on else None),
+            'images_per_s_per_gpu': None if dry else round(images_per_s / world, 3), 'per_rank': per_rank, 'affinity': pinned,
             'weights_profile': args.weights, 'trained_like': trained,
             'step_ms': {'mean': round(sum(step_ms) / len(step_ms), 3), 'min': round(min(step_ms), 3), 'max': round(max(step_ms), 3),
                         'std': round((sum((t - sum(step_ms) / len(step_ms)) ** 2 for t in step_ms) / len(step_ms)) ** 0.5, 3),

@@ -2,8 +2,11 @@
 (the reference loop is b=1), so a batch is split into contiguous per-rank shards and
 NOTHING is exchanged inside the loop.  Collectives (RCCL over xGMI when the backend is 'nccl'; gloo
 in the CPU tests): one broadcast of the packed frozen weights at start-up, an optional all_gather of
-the per-rank outputs at the end.  xGMI is point-to-point with 7 links per GPU, so the single 34 MB
-broadcast is a flat fan-out from rank 0; no bucketing or ring tuning is needed for this path."""
+the per-rank outputs at the end.  The broadcast is ONE ``dist.broadcast`` of the 34 MB blob: which
+algorithm RCCL runs for it over the point-to-point xGMI links (ring, tree, direct) is RCCL's choice and has
+never been observed here - no box with more than one GPU was available in any round; at 34 MB, once per
+process, it does not matter for the throughput.  No bucketing or ring tuning exists because nothing is
+exchanged in the loop."""
 import torch
 import torch.distributed as dist
 

@@ -143,9 +143,15 @@ def build_depther(cfg, train_cfg=None, test_cfg=None):
     return build_segmentor(cfg, train_cfg, test_cfg)
 
 
-def register_into_mmseg():
-    """Register the MI355X classes over the reference ones in an installed mmseg / depth toolbox.
+def register_into_mmseg(package='mmseg', depth_package='depth'):
+    """Register the MI355X classes over the reference ones in an importable mmseg / depth toolbox.
+    ``package`` / ``depth_package``: the dotted name the toolbox is importable under - the top-level ``mmseg`` / ``depth`` of
+    segmentation/ and depth/, equally the copy the ControlNet demo ships (controlnet/annotator/ddp/mmseg, put on sys.path as
+    top-level ``mmseg`` by controlnet/annotator/ddp/__init__.py:2 and used by controlnet/gradio_seg2image_ddp.py:2,24,35), or a
+    tree vendored under another root (``package='annotator.ddp.mmseg'``).  Names a toolbox does not define (the ControlNet copy has
+    no SelfAlignedDDP) are registered all the same - a config that never asks for them never sees them.
     Returns the list of registries touched (empty when none is importable)."""
+    import importlib
     touched = []
     from .segmentors.ddp import DDP, SelfAlignedDDP
     from .decode_heads.deformable_head_with_time import DeformableHeadWithTime
@@ -153,7 +159,8 @@ def register_into_mmseg():
     # only "toolbox not installed" is tolerated: a failure half way through a registration would leave a partial
     # drop-in behind and must surface
     try:
-        from mmseg.models.builder import SEGMENTORS as MS, HEADS as MH, NECKS as MN
+        bld = importlib.import_module(package + '.models.builder')
+        MS, MH, MN = bld.SEGMENTORS, bld.HEADS, bld.NECKS
     except ImportError:
         MS = None
     if MS is not None:
@@ -165,15 +172,16 @@ def register_into_mmseg():
         MH.register_module(name='DeformableHeadWithTime', force=True, module=DeformableHeadWithTime)
         from .decode_heads.fcn_head_with_time import FCNHeadWithTime
         MH.register_module(name='FCNHeadWithTime', force=True, module=FCNHeadWithTime)
-        touched.append('mmseg')
+        touched.append(package)
     try:
-        from depth.models.builder import DEPTHER as DD, HEADS as DH
+        bld = importlib.import_module(depth_package + '.models.builder')
+        DD, DH = bld.DEPTHER, bld.HEADS
     except ImportError:
         DD = None
     if DD is not None:
         DD.register_module(name='DDP', force=True, module=DepthDDP)
         DH.register_module(name='DeformableHeadWithTime', force=True, module=DepthDeformableHeadWithTime)
-        touched.append('depth')
+        touched.append(depth_package)
     return touched
 
 

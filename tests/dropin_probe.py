@@ -6,6 +6,8 @@ tests/test_dropin_reference_registry.py (the import mutates sys.modules and the 
 
     python tests/dropin_probe.py seg     # segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py
     python tests/dropin_probe.py depth   # depth/configs/ddp_kitti/ddp_swint_1k_w7_kitti_bs2x8_scale01.py
+    python tests/dropin_probe.py controlnet   # the mmseg copy of the ControlNet demo (controlnet/annotator/ddp/mmseg, imported as
+                                              # top-level ``mmseg`` the way controlnet/annotator/ddp/__init__.py:2 does) on the ADE config
 
 Steps: (1) build the shipped config with the reference's ``build_segmentor`` / ``build_depther`` -> the reference model;
 (2) ``ddp_amd.register_into_mmseg()``; (3) build the SAME config with the SAME reference builder again
@@ -74,7 +76,18 @@ def call_like_the_harness(model, task):
 
 def main(task):
     import ref_shim
-    if task == 'seg':
+    flavour = task
+    if task == 'controlnet':
+        # the copy under controlnet/ FIRST on sys.path: ``mmseg`` resolves to it, not to segmentation/mmseg
+        ref_shim.install()
+        sys.path.insert(0, os.path.join(ref_shim.REF, 'controlnet', 'annotator', 'ddp'))
+        from mmcv import Config
+        from mmseg.models import build_segmentor as build
+        import mmseg
+        assert os.path.join('controlnet', 'annotator', 'ddp') in mmseg.__file__, mmseg.__file__
+        cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
+        task = 'seg'
+    elif task == 'seg':
         build, Config, _ = ref_shim.import_seg()
         cfg_path = os.path.join(ref_shim.REF, 'segmentation/configs/ade/ddp_swin_t_2x8_512x512_160k_ade20k.py')
     else:
@@ -85,6 +98,8 @@ def main(task):
         m = Config.fromfile(cfg_path).model
         m.backbone.init_cfg = None          # no checkpoint download
         m.train_cfg = None
+        if flavour == 'controlnet':         # that copy's DDP predates ``accumulation`` (its ddp.py has no such argument)
+            m.pop('accumulation', None)
         return m
 
     ref = build(model_cfg())
@@ -92,7 +107,7 @@ def main(task):
     assert ref_cls['segmentor'].__module__.split('.')[0] in ('mmseg', 'depth'), ref_cls
 
     import ddp_amd
-    touched = ddp_amd.register_into_mmseg()
+    touched = ddp_amd.register_into_mmseg(package='mmseg') if flavour == 'controlnet' else ddp_amd.register_into_mmseg()
     assert ('mmseg' if task == 'seg' else 'depth') in touched, touched
     ours = build(model_cfg())
 
@@ -118,7 +133,7 @@ def main(task):
     res = ours.load_state_dict({k: v for k, v in ref.state_dict().items() if not k.startswith('auxiliary_head.')}, strict=True)
     hot = [k for k in b if not k.startswith(('backbone.', 'neck.'))]
     called = call_like_the_harness(ours, task)
-    print(json.dumps(dict(task=task, touched=touched, segmentor=f'{mod(ours)}.{type(ours).__name__}',
+    print(json.dumps(dict(task=flavour, touched=touched, segmentor=f'{mod(ours)}.{type(ours).__name__}',
                           head=f'{mod(ours.decode_head)}.{type(ours.decode_head).__name__}', necks=necks,
                           backbone=f'{mod(ours.backbone)}.{type(ours.backbone).__name__}', keys=len(b), hot_path_keys=len(hot),
                           hot_path_params=int(sum(ours.state_dict()[k].numel() for k in hot)), strict_load=str(res),

