@@ -911,7 +911,13 @@ def main():
                     continue
                 for name, e in d.items():
                     if key in name and 'hbm_read_bytes_per_launch' in e:
-                        roofline['traffic'] = int(e['hbm_read_bytes_per_launch'] + e.get('hbm_write_bytes_per_launch_uncalibrated', 0))
+                        # writes: calibrated on the profiled box by a known-byte streaming kernel when the summary carries the factor
+                        wr = e.get('hbm_write_bytes_per_launch', e.get('hbm_write_bytes_per_launch_uncalibrated', 0))
+                        roofline['traffic'] = int(e['hbm_read_bytes_per_launch'] + wr)
+                        cal = d.get('_meta', {}).get('hbm_calibration')
+                        roofline['traffic_calibration'] = ({'write_factor': cal.get('write_factor_applied'), 'read_factor': 2.0,
+                                                            'read_factor_measured': cal.get('read_factor_measured')}
+                                                           if cal and 'hbm_write_bytes_per_launch' in e else None)
                         roofline['traffic_source'] = os.path.basename(summ) + ' (same kernel sources, sha ' + cur + ')'
                         break
                 if roofline['traffic'] is not None:

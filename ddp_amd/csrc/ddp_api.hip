@@ -878,6 +878,24 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     DDP_TRY(launch_b3_linear(o.in_sb, o.wp_m, nullptr, nullptr, 0, 0, 0, o.feat0, 256, M0, 256, 256, st, TAG_FEAT));   // u_0 = W_m . noise
   }
   unsigned char* bev_code = reinterpret_cast<unsigned char*>(o.logits);            // (M) the step's x0 code per head-grid token
+  auto depth_update_args = [&](const ddp_step& stp) {
+    DepthUpdateArgs a;
+    a.taps = o.logits;
+    a.bias = 0.f;
+    a.bias_ptr = weights->head_b;
+    a.depth_t = o.mask;
+    a.pred = o.pred;
+    a.B_r = o.R;
+    a.h = o.h;
+    a.w = o.w;
+    a.min_depth = cfg->min_depth;
+    a.max_depth = cfg->max_depth;
+    a.bit_scale = cfg->bit_scale;
+    a.scale_up = (cfg->flags & DDP_FLAG_DEPTH_SCALE_UP) ? 1 : 0;      // decode_head.py:252-262
+    a.eps_depth = (cfg->flags & DDP_FLAG_DEPTH_NO_EPS) ? (a.scale_up ? 1.0f : 0.0f) : (a.scale_up ? cfg->max_depth : cfg->min_depth);
+    a.st = stp;
+    return a;
+  };
   for (int s = 0; s < o.K; ++s) {
     const ddp_step& sp = steps[s];
     const float* aff = o.aff + size_t(s) * o.L * 512;
@@ -901,6 +919,13 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       pj.px = o.px[0];
       pj.n_tok = o.Nh;
       pj.w = o.wh;
+      // fused step boundary: the PREVIOUS step's DDIM update (from the taps its last layer's tail left) runs in front of this head
+      DepthUpdateArgs prev;
+      pj.upd = nullptr;
+      if (depth_lt && s > 0) {
+        prev = depth_update_args(steps[s - 1]);
+        pj.upd = &prev;
+      }
       DDP_TRY(launch_b3_l0proj(pj, st));
       depth_head = true;
     } else if (cfg->task == DDP_TASK_DEPTH) {
@@ -1059,22 +1084,9 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       } else {
         DDP_TRY(launch_linear(o.q, 256, true, o.wtap, 256, nullptr, nullptr, 0, 0, 0, o.logits, 32, M, 9, 256, 0, st, TAG_HEAD));
       }
-      DepthUpdateArgs a;
-      a.taps = o.logits;
-      a.bias = 0.f;
-      a.bias_ptr = weights->head_b;
-      a.depth_t = o.mask;
-      a.pred = o.pred;
-      a.B_r = o.R;
-      a.h = o.h;
-      a.w = o.w;
-      a.min_depth = cfg->min_depth;
-      a.max_depth = cfg->max_depth;
-      a.bit_scale = cfg->bit_scale;
-      a.scale_up = (cfg->flags & DDP_FLAG_DEPTH_SCALE_UP) ? 1 : 0;      // decode_head.py:252-262
-      a.eps_depth = (cfg->flags & DDP_FLAG_DEPTH_NO_EPS) ? (a.scale_up ? 1.0f : 0.0f) : (a.scale_up ? cfg->max_depth : cfg->min_depth);
-      a.st = sp;
-      DDP_TRY(launch_depth_update(a, st));
+      // the update of every step but the last runs inside the next step's head (k_layer MODE 3) on the fused path; the last step's
+      // (and every step's on the other paths) here: it also leaves the metric depth prediction the output is made of
+      if (!(depth_lt && s + 1 < o.K)) DDP_TRY(launch_depth_update(depth_update_args(sp), st));
     } else {
       if (o.b3)
         DDP_TRY(launch_b3_linear(o.q_sb, o.wp_head, weights->head_b, nullptr, 0, 0, 0, o.logits, 32, M, o.Kc, 256, st, TAG_HEAD));

@@ -299,6 +299,25 @@ int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st) {
   la.px = a.px;
   la.n_tok = a.n_tok;
   la.w = a.w;
+  if (a.upd) {
+    const DepthUpdateArgs& u = *a.upd;
+    if (!a.res || !a.dvec || u.depth_t != a.dvec || u.B_r * u.h * u.w != a.M || u.h * u.w != a.n_tok || u.w != a.w) {
+      set_error("layer 0 projections: the fused depth update needs the depth head's own map");
+      return DDP_E_BADCFG;
+    }
+    la.dtaps = u.taps;
+    la.dbias = u.bias_ptr;
+    la.dvec_rw = u.depth_t;
+    la.d_min = u.min_depth;
+    la.d_max = u.max_depth;
+    la.d_bit = u.bit_scale;
+    la.d_eps = u.eps_depth;
+    la.d_scale_up = u.scale_up;
+    la.d_sig = u.st.sigma;
+    la.d_alpha = u.st.alpha;
+    la.d_alpha_next = u.st.alpha_next;
+    la.d_sigma_next = u.st.sigma_next;
+  }
   static LdsAttrOnce attr;
   attr.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_VALUE, 3>), int(b3::LYR_LDS_B));
   const int n_cu = cu_count();

@@ -178,6 +178,7 @@ int launch_b3_prologue(const PrologueLaunch& a, hipStream_t st);
 int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const float* nchw_x, const float* bias, hipStream_t st);
 // layer 0's value / sampling projections alone (k_layer MODE 3): q given as SB (res == nullptr), or formed as the depth
 // concat-conv q = res[row] + wm * dvec[m] and written to Q.  stream = the 11 projection images, bias_ext as PrologueLaunch.
+struct DepthUpdateArgs;
 struct L0ProjLaunch {
   float* Q;                        // fp32 fragment-major q (in; out when formed here)
   const unsigned char* stream;
@@ -191,6 +192,9 @@ struct L0ProjLaunch {
   float* samp_out;
   const float *py, *px;
   int n_tok, w;
+  // depth, steps >= 1: the previous step's DDIM update (k_depth_update's arithmetic on the taps the previous step's last layer left)
+  // runs inside this launch, in front of the head; upd == nullptr: dvec is used as it is
+  const struct DepthUpdateArgs* upd;
 };
 int launch_b3_l0proj(const L0ProjLaunch& a, hipStream_t st);
 // stream GEMM of the necks (k_layer MODE 5): up to four problems in one persistent launch, tiles in the order given

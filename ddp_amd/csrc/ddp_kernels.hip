@@ -1836,33 +1836,55 @@ __global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ 
 // - the first term is loop invariant, and u follows the DDIM update affinely because x0 is one of 2^K rows of a table (the
 // thresholded maps select a mean embedding, :290-295): u' = ua u + uc T[code], T = LUT . W_m^T.
 // q[(b r + ri) Nh + n] (fragment-major) = rx[b Nh + n] (row-major, shared by the r replicas) + resample(u[(b r + ri)])[n]
+// One block = one 32-token group of the fragment-major q: each of its 4 waves forms 8 tokens' rows (a row = 64 lanes x 16 B: the four
+// corner rows of u and the row of rx are coalesced 1-KiB loads), the rows meet in LDS and leave in fragment order - 8 coalesced 1-KiB
+// stores per wave instead of 64 scattered 16-B pieces per token (0.285 -> ms per launch at C5, profiles/r06*).
 __global__ void __launch_bounds__(256) k_bev_q(const float* __restrict__ u, const float* __restrict__ rx, float* __restrict__ q_blk, int R,
                                                 int r, BevGeom g) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) float tile[32][260];        // +4 floats per row: the fragment-order reads spread over the banks
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Nh = g.hh * g.wh, N = g.h * g.w;
-  if (m >= R * Nh) return;
-  const int img = m / Nh, n = m - img * Nh;
-  const int oi = n / g.wh, oj = n - oi * g.wh;
-  const float y = bev_src_coord(g, 0, oi, g.h);
-  const float x = bev_src_coord(g, 1, oj, g.w);
-  const float xf = floorf(x), yf = floorf(y);
-  const float fx = x - xf, fy = y - yf;
-  const int x0 = int(xf), y0 = int(yf);
-  const float* base = u + size_t(img) * N * 256 + lane * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int M = R * Nh;
+  const int m0 = blockIdx.x * 32;
+#pragma unroll 2
+  for (int k = 0; k < 8; ++k) {
+    const int jt = wave * 8 + k;
+    const int m = m0 + jt;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const int img = m / Nh, n = m - img * Nh;
+      const int oi = n / g.wh, oj = n - oi * g.wh;
+      const float y = bev_src_coord(g, 0, oi, g.h);
+      const float x = bev_src_coord(g, 1, oj, g.w);
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int x0 = int(xf), y0 = int(yf);
+      const float* base = u + size_t(img) * N * 256 + lane * 4;
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
+      for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int xx = x0 + dx, yy = y0 + dy;
-      if (xx >= 0 && xx < g.w && yy >= 0 && yy < g.h) {
-        const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
-        acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
-      }
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = x0 + dx, yy = y0 + dy;
+          if (xx >= 0 && xx < g.w && yy >= 0 && yy < g.h) {
+            const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
+            acc += *reinterpret_cast<const f32x4*>(base + size_t(yy * g.w + xx) * 256) * wgt;
+          }
+        }
+      acc += *reinterpret_cast<const f32x4*>(rx + (size_t(img / r) * Nh + n) * 256 + lane * 4);
     }
-  acc += *reinterpret_cast<const f32x4*>(rx + (size_t(img / r) * Nh + n) * 256 + lane * 4);
-  *reinterpret_cast<f32x4*>(q_blk + blk_off256(m, lane * 4)) = acc;
+    *reinterpret_cast<f32x4*>(&tile[jt][lane * 4]) = acc;
+  }
+  __syncthreads();
+  // fragment f = (t, g) * 64 + lane64, lane64 = h * 32 + j: channels 32 t + 8 g + 4 h .. + 3 of token j (gemm_f32.h)
+  float* dst = q_blk + size_t(blockIdx.x) * 8192;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int f = k * 256 + threadIdx.x;
+    const int tg = f >> 6, l64 = f & 63;
+    const int j = l64 & 31, h = l64 >> 5;
+    const int ch = (tg >> 2) * 32 + (tg & 3) * 8 + 4 * h;
+    *reinterpret_cast<f32x4*>(dst + size_t(f) * 4) = *reinterpret_cast<const f32x4*>(&tile[j][ch]);
+  }
 }
 
 // LUT64[code][c] = (sigmoid(mean_k E[bit k of code ? k + 1 : 0][c]) * 2 - 1) * bit_scale: the 2^K values x0 can take at a pixel
@@ -2220,7 +2242,7 @@ int launch_bev_resample(const float* feat, float* out, int R, const BevGeom& g, 
   return check_launch("k_bev_resample");
 }
 int launch_bev_q(const float* u, const float* rx, float* q_blk, int R, int r, const BevGeom& g, hipStream_t st) {
-  hipLaunchKernelGGL(k_bev_q, dim3(cdiv(long(R) * g.hh * g.wh, 4)), dim3(256), 0, st, u, rx, q_blk, R, r, g);
+  hipLaunchKernelGGL(k_bev_q, dim3(cdiv(long(R) * g.hh * g.wh, 32)), dim3(256), 0, st, u, rx, q_blk, R, r, g);    // (q holds whole 256-token tiles)
   return check_launch("k_bev_q");
 }
 int launch_build_bev_lut(const float* emb, float* lut, int K, float bit_scale, hipStream_t st) {

@@ -130,6 +130,14 @@ struct LayerArgs {
   // its grid resampling, ddp_head_forward) or is formed here as the depth concat-conv, whose noisy-map half has ONE input
   // channel: q = res[row(m)] + wm * dvec[m]  (depth/depth/models/depther/ddp.py:236-237; wm travels as `bo`)
   const float* dvec;             // (M) noisy depth map
+  // MODE 3, depth, steps >= 1: the DDIM update of the PREVIOUS step runs here, in front of the head (k_depth_update's arithmetic,
+  // depth/depth/models/depther/ddp.py:238-246): d' from the nine taps the previous step's last layer left (MODE 9) - no launch
+  // between the steps.  dtaps == nullptr: dvec is read as it is.
+  const float* dtaps;            // (M, 32) per-tap dot products of conv_depth (column dy*3+dx)
+  const float* dbias;            // conv_depth's bias (1)
+  float* dvec_rw;                // = dvec, written
+  float d_min, d_max, d_bit, d_eps, d_sig, d_alpha, d_alpha_next, d_sigma_next;
+  int d_scale_up;
   // MODE 7 (first step's head from NCHW): S = nullptr; noise / x planes (maps of n_tok tokens, 256 channels each; one noisy map
   // per image), `bo` = the concat-conv's bias, res = xproj OUT (fp32 rows of 256), ubuf = u_0 out
   const float* nchw_noise;
@@ -919,7 +927,30 @@ k_layer(LayerArgs la) {
         mr = mr < M ? mr : M - 1;
         const size_t row = la.res_rn ? size_t(mr / la.res_rn) * la.n_tok + mr % la.n_tok : size_t(mr);
         const float* rp = la.res + row * 256 + 4 * h;
-        const float dv = la.dvec[mr];
+        float dv = la.dvec[mr];
+        if (la.dtaps) {                                       // (uniform) the previous step's depth update, then this step's head
+          int ntk3 = la.n_tok, wm3 = la.w;
+          asm volatile("" : "+s"(ntk3), "+s"(wm3));           // (opaque per tile: see P3's index arithmetic)
+          const int img3 = mr / ntk3, n3 = mr - img3 * ntk3;
+          const int i3 = n3 / wm3, j3 = n3 - i3 * wm3, hm3 = ntk3 / wm3;
+          const float* tb = la.dtaps + size_t(img3) * ntk3 * 32;
+          float sacc = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int ii = i3 + dy - 1, jj = j3 + dx - 1;
+              if (ii >= 0 && ii < hm3 && jj >= 0 && jj < wm3) sacc += tb[size_t(ii * wm3 + jj) * 32 + dy * 3 + dx];
+            }
+          sacc += la.dbias[0];
+          const float pred = la.d_scale_up ? la.d_eps / (1.0f + expf(-sacc)) : fmaxf(sacc, 0.f) + la.d_eps;
+          float x0 = (pred - la.d_min) / (la.d_max - la.d_min);
+          x0 = (x0 * 2.0f - 1.0f) * la.d_bit;
+          x0 = fminf(fmaxf(x0, -la.d_bit), la.d_bit);
+          const float epsn = la.d_sig * (dv - la.d_alpha * x0);
+          dv = la.d_alpha_next * x0 + la.d_sigma_next * epsn;
+          if (h == 0 && m_base + j < M) la.dvec_rw[mr] = dv;
+        }
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
           f32x4 xx[2][4];

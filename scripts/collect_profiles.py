@@ -34,6 +34,23 @@ def pmc(dirname):
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
 
 
+# ---- calibration of the two counters against kernels that move exactly 1 GiB (scripts/ubench/hbm_calib.hip, same box, same passes)
+GIB = float(1 << 30)
+calib = {}
+cal_wr, cal_rd = pmc('pmc_calib_wr'), pmc('pmc_calib_rd')
+for k, d in cal_wr.items():
+    if 'WRITE_SIZE' in d and d['WRITE_SIZE'][0] > 0 and (k.startswith('k_store') or k.startswith('k_copy')):
+        calib.setdefault(k, {})['write_factor'] = round(GIB / (d['WRITE_SIZE'][0] * 1024), 4)     # known bytes / (counter KB x 1024)
+        calib[k]['write_size_raw_kb'] = round(d['WRITE_SIZE'][0], 1)
+for k, d in cal_rd.items():
+    if 'FETCH_SIZE' in d and d['FETCH_SIZE'][0] > 0 and (k.startswith('k_load') or k.startswith('k_copy')):
+        calib.setdefault(k, {})['read_factor'] = round(GIB / (d['FETCH_SIZE'][0] * 1024), 4)
+        calib[k]['fetch_size_raw_kb'] = round(d['FETCH_SIZE'][0], 1)
+# the factors applied below: the non-temporal 16-B pattern is what the layer kernels' big streams use; reads keep the guide's x2
+# unless the box says otherwise
+WF = calib.get('k_store16_nt', {}).get('write_factor')
+RF = calib.get('k_load16_nt', {}).get('read_factor') or calib.get('k_load16', {}).get('read_factor')
+
 summary = {}
 hbm = pmc('pmc_hbm_rd')
 for k, d in pmc('pmc_hbm_wr').items():
@@ -46,6 +63,8 @@ for k, d in hbm.items():
         e['fetch_size_raw_kb'] = round(d['FETCH_SIZE'][0], 1)
     if 'WRITE_SIZE' in d:
         e['hbm_write_bytes_per_launch_uncalibrated'] = round(d['WRITE_SIZE'][0] * 1024)
+        if WF:
+            e['hbm_write_bytes_per_launch'] = round(d['WRITE_SIZE'][0] * 1024 * WF)              # calibrated on this box
 for k, d in pmc('pmc_mfma').items():
     e = summary.setdefault(k, {})
     for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY'):
@@ -64,7 +83,16 @@ out = dict(rows)
 # provenance: the hash of the kernel sources the GPU box ran (scripts/gpu_round.sh wrote it next to the counters)
 meta_f = os.path.join(src, 'source_sha.txt')
 if os.path.exists(meta_f):
-    out['_meta'] = {'source_sha': open(meta_f).read().strip(), 'tag': tag}
+    out['_meta'] = {'source_sha': open(meta_f).read().strip().split()[0], 'tag': tag}
+    if calib:
+        out['_meta']['hbm_calibration'] = {
+            'kernels': calib, 'write_factor_applied': WF, 'read_factor_measured': RF, 'read_factor_applied': 2.0,
+            'note': 'factor = bytes the kernel moved (1 GiB) / (counter KB x 1024), scripts/ubench/hbm_calib.hip under the same rocprofv3 '
+                    'passes on the same box; hbm_write_bytes_per_launch = WRITE_SIZE x write_factor_applied (k_store16_nt: the layer '
+                    "kernels' stream pattern); reads keep the guide's x2 (read_factor_measured beside it)"}
+    cj = os.path.join(src, 'hbm_calib.jsonl')
+    if os.path.exists(cj):
+        out['_meta']['hbm_stream_rates'] = [json.loads(l) for l in open(cj) if l.startswith('{')]
 rows = list(out.items())
 json.dump(dict(rows), open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 for pat, name in (('prof/**/*kernel_stats.csv', f'{tag}_kernel_stats.csv'),

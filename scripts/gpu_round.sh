@@ -34,6 +34,13 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/p
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_rd -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_rd.log 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_hbm_wr -o ddp -- $BENCH > $REPO/$OUT/pmc_hbm_wr.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $REPO/$OUT/pmc_mfma -o ddp -- $BENCH > $REPO/$OUT/pmc_mfma.log 2>&1
+# calibration of the two HBM counters on THIS box: known-byte streaming kernels in the library's access patterns (1 GiB each,
+# scripts/ubench/hbm_calib.hip) under the same two passes -> factor = known bytes / counted bytes (collect_profiles.py, _meta.hbm_calibration)
+CAL=$REPO/scripts/ubench/hbm_calib
+[ -x $CAL ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $CAL $REPO/scripts/ubench/hbm_calib.hip
+$CAL > $REPO/$OUT/hbm_calib.jsonl 2> $REPO/$OUT/hbm_calib.err
+timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_calib_wr -o cal -- $CAL > $REPO/$OUT/pmc_calib_wr.log 2>&1
+timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_calib_rd -o cal -- $CAL > $REPO/$OUT/pmc_calib_rd.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_ade_swin_t_k3_1x512x1024 -o ddp -- python $REPO/bench.py --workload ade_swin_t_k3_1x512x1024 --steps 20 --warmup 2 --no-cpu-baseline --no-roofline --no-power > $REPO/$OUT/prof_b1.log 2>&1
 # the other BASELINE configurations (per-GPU shards): kernel stats + MFMA-busy counters each
 WLS="city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200"

@@ -62,8 +62,9 @@ SEG_CASES = [
     dict(name='seg_td2', h=8, w=11, num_classes=150, timesteps=4, randsteps=2, bit_scale=0.01,
          accumulation=False, noise_schedule='cosine', diffusion='ddim', seed=7, trace=False, time_difference=2),
     # content-dependent weight profiles (ddp_amd/utils/synthetic.py PROFILES; VERDICT r05 "next" #4): sampling offsets that react
-    # to the query by +- 2.4 px ('trained_like') and by +- 6 px ('wide_offsets': every tap group leaves the gather's staged
-    # window), peaked attention, 8x class scores - on a small map
+    # to the query by +- 2.4 px, peaked attention, 8x class scores ('trained_like': the network amplifies rounding - the reference is
+    # 1.1e-3 from its own fp64 evaluation on this map with every decision equal), and points spread +- 6 px around their head's mean
+    # ('wide_offsets': every tap group leaves the gather's staged window, many taps leave the map) - on a small map
     dict(name='seg_trained_small', h=24, w=40, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01,
          accumulation=True, noise_schedule='cosine', diffusion='ddim', seed=8, trace=False, profile='trained_like'),
     dict(name='seg_wide_offsets', h=24, w=40, num_classes=19, timesteps=3, randsteps=1, bit_scale=0.01,

@@ -279,9 +279,10 @@ def _finish_free_running(results):
                      'profiles/r03w_reference_drift_c3.txt, r03v_parity_sweep_c3_image0.txt); (i), (ii), (a), (b) hold: ' + ' | '.join(bad))
 
 
-def _seg_fullsize(tag, name, dev, oracle_free_running=None, single_step_fp64=False):
+def _seg_fullsize(tag, name, dev, oracle_free_running=None, single_step_fp64=False, more=()):
     """the engine on the whole per-GPU batch of a configuration (record_x0), image ``b`` against the reference fixture ``name``
-    (+ the CPU oracle on that image when ``oracle_free_running`` names its variants)"""
+    (+ the CPU oracle on that image when ``oracle_free_running`` names its variants).  ``more``: further reference fixtures of OTHER
+    images of the same seeded batch (round 6: a second image per configuration), compared from the same engine run."""
     from ddp_amd.engine import DDPEngine
     from oracle import ddp_oracle as O
     cfg, sd, x, noise, g = load_fullsize_case(name)
@@ -300,6 +301,13 @@ def _seg_fullsize(tag, name, dev, oracle_free_running=None, single_step_fp64=Fal
         assert torch.equal(e2.sample(dx, dn).cpu(), out)
         del e2
     res = _seg_parity_with_reference(tag, name, dev, out[b:b + 1], trace, cfg, sd, x[b:b + 1].contiguous(), noise[b:b + 1].contiguous(), g)
+    for other in more:
+        cfg2, sd2, x2, noise2, g2 = load_fullsize_case(other)
+        assert {k: cfg2[k] for k in ('B', 'h', 'w', 'timesteps', 'num_classes', 'sd_seed', 'in_seed')} == \
+               {k: cfg[k] for k in ('B', 'h', 'w', 'timesteps', 'num_classes', 'sd_seed', 'in_seed')}, 'another batch'
+        b2 = cfg2['b']
+        _seg_parity_with_reference(tag, other, dev, out[b2:b2 + 1], eng.x0_trace()[:, b2].cpu(), cfg2, sd, x[b2:b2 + 1].contiguous(),
+                                   noise[b2:b2 + 1].contiguous(), g2)
     results = []
     if oracle_free_running:
         results.append(_seg_parity_with_decisions(tag, eng, out, x, noise, sd, b, K, acc, oracle_free_running))
@@ -318,18 +326,18 @@ def _seg_fullsize(tag, name, dev, oracle_free_running=None, single_step_fp64=Fal
 
 def test_c2_ade_8x512x1024_k3(dev):
     """BASELINE configs[1]: 8 images of 128x256 tokens, 150 classes, 3-step DDIM with accumulation.  Image 0 against the
-    reference fixture full_c2 (teacher-forced + free-running) and against the CPU oracle (decisions fed + free-running with the
+    reference fixtures full_c2 / full_c2_b5 - two images of the batch - (teacher-forced + free-running) and against the CPU oracle (decisions fed + free-running with the
     reference-vs-reference yardstick: the one oracle free-running comparison kept in the suite)."""
-    res, results = _seg_fullsize('C2', 'full_c2', dev, oracle_free_running=('taps', 'fp64'), single_step_fp64=True)
+    res, results = _seg_fullsize('C2', 'full_c2', dev, oracle_free_running=('taps', 'fp64'), single_step_fp64=True, more=('full_c2_b5',))
     _finish_free_running(results)
 
 
 def test_c3_cityscapes_4x1024x2048_k10(dev):
     """BASELINE configs[2], one GPU's shard: 4 images of 256x512 tokens (524 288 tokens per launch), 19 classes, 10-step DDIM
-    (Cityscapes configs: accumulation off -> last-step scores).  Image 2 against the reference fixture full_c3: ten steps of
+    (Cityscapes configs: accumulation off -> last-step scores).  Images 2 and 0 against the reference fixtures full_c3 / full_c3_b0: ten steps of
     argmax feedback on 131 072 pixels, teacher-forced to rounding, free-running localised.  (The three CPU-oracle runs per image
     of earlier rounds - ~6 of GPUTEST's 11 minutes - are scripts/parity_sweep.py --config c3.)"""
-    _seg_fullsize('C3', 'full_c3', dev)
+    _seg_fullsize('C3', 'full_c3', dev, more=('full_c3_b0',))
 
 
 def test_c4_kitti_depth_16x352x1216_k20(dev):
@@ -444,6 +452,41 @@ def test_c2_size_trained_like_weights(dev):
     print(f'C2-size, trained-like weights, K = {K} (probabilities, decisions fed): gpu vs fp64 oracle max {dg:.3e}; '
           f'fp32 oracle vs fp64 oracle max {dc:.3e}; final argmax agreement with fp64: gpu {agree:.6f}, fp32 oracle {agree_c:.6f}')
     assert dg <= 4 * dc + 1e-5 and agree >= agree_c - 2e-3
+    # ---- the same image against what THE REFERENCE produced with these weights (tests/golden/full_c2_trained.npz,
+    # gen_golden.py --task fullsize_seg, the seeds above).  The network amplifies rounding here, so the yardstick is the reference's OWN
+    # distance to an fp64 evaluation under the same (reference) decisions; the engine is teacher-forced with those decisions too.
+    cfg_t, sd_t, x_t, noise_t, gt = load_fullsize_case('full_c2_trained')
+    assert (cfg_t['B'], cfg_t['b'], cfg_t['h'], cfg_t['w'], cfg_t['timesteps'], cfg_t['num_classes']) == (B, b, h, w, K, ncls)
+    assert torch.equal(x_t, x) and torch.equal(noise_t, noise)
+    ref_dec = gt['decisions'].long()                                            # (K,h,w)
+    eng_f = DDPEngine(sd, 'seg', h=h, w=w, batch=1, randsteps=1, timesteps=K, num_classes=ncls, bit_scale=0.01, accumulation=True,
+                      device=dev, force_x0=True)
+    eng_f.set_x0_decisions(ref_dec.unsqueeze(1))
+    out_f = eng_f.sample(x[b:b + 1].contiguous().to(dev), noise[b:b + 1].contiguous().to(dev)).cpu()
+    own = eng_f.x0_trace()[:, 0].cpu().long()
+    r64f = O.ddim_sample_seg(x[b:b + 1].double(), noise[b].double(), _dbl(sd), timesteps=K, randsteps=1, bit_scale=0.01, accumulation=True,
+                             x0_index=[ref_dec[s].unsqueeze(0) for s in range(K)])
+    idx_t = torch.arange(0, h * w, cfg_t['stride'])
+    absmax = float(gt['out_absmax'])
+    e_gpu = float((out_f[0].reshape(ncls, -1)[:, idx_t] - gt['out_sub']).abs().max()) / absmax
+    e_ref64 = float((r64f[0].float().reshape(ncls, -1)[:, idx_t] - gt['out_sub']).abs().max()) / absmax
+    wp = class_projection_weights(ncls).view(-1, 1, 1)
+    p_gpu = float(((out_f[0] * wp).sum(0) - gt['out_proj']).abs().max()) / float(gt['out_proj'].abs().max())
+    differ = own != ref_dec
+    gap, scale = gt['gap'].float(), gt['score_scale'].float()
+    worst = max((float((gap[s][differ[s]] / scale[s]).max()) for s in range(K) if bool(differ[s].any())), default=0.0)
+    agree_f = float((out_f[0].argmax(0) == gt['final_cls'].long()).float().mean())
+    agree_ref64 = float((r64f[0].argmax(0) == gt['final_cls'].long()).float().mean())     # the fp64 oracle's own agreement with the reference
+    # free-running product path (the batch run above) against the reference's free-running output: decisions and final classes
+    d_free = eng.x0_trace()[:, b].cpu().long() != ref_dec
+    agree_free = float((out[b].argmax(0) == gt['final_cls'].long()).float().mean())
+    record(f'C2-size trained-like vs REFERENCE fixture full_c2_trained, reference decisions fed: max-rel {e_gpu:.3e} on every {cfg_t["stride"]}th '
+           f'pixel x all classes ({p_gpu:.3e} on the every-pixel projection); the reference itself is {e_ref64:.3e} from the fp64 oracle under the '
+           f'same decisions; {int(differ.sum())} of {differ.numel()} own step decisions differ from the reference\'s (largest reference top-2 gap '
+           f'there {worst:.3e} of the score scale); final class map agreement {agree_f:.6f} (fp64 oracle vs the reference: {agree_ref64:.6f}); '
+           f'free-running: {int(d_free.sum())} decisions differ, final class map agreement {agree_free:.6f} - recorded, not asserted: with '
+           f'this profile the reference is chaotic at rounding level (the fp64 figures beside it)')
+    assert e_gpu <= 4 * e_ref64 + 1e-5 and agree_f >= agree_ref64 - 2e-3
 
 
 @pytest.mark.slow
