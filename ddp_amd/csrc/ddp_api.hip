@@ -598,6 +598,7 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         pj.res_rn = 0;
         pj.wm = nullptr;
         pj.dvec = nullptr;
+        pj.upd = nullptr;
         pj.M = M;
         pj.v_out = o.vpad;
         pj.samp_out = o.samp;

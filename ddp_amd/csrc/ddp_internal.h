@@ -179,7 +179,7 @@ int launch_b3_head_nchw(const PrologueLaunch& a, const float* nchw_noise, const 
 // layer 0's value / sampling projections alone (k_layer MODE 3): q given as SB (res == nullptr), or formed as the depth
 // concat-conv q = res[row] + wm * dvec[m] and written to Q.  stream = the 11 projection images, bias_ext as PrologueLaunch.
 struct DepthUpdateArgs;
-struct L0ProjLaunch {
+struct L0ProjLaunch {   // (plain aggregate: every field is set by the caller)
   float* Q;                        // fp32 fragment-major q (in; out when formed here)
   const unsigned char* stream;
   const float* bias_ext;

@@ -934,14 +934,20 @@ k_layer(LayerArgs la) {
           const int img3 = mr / ntk3, n3 = mr - img3 * ntk3;
           const int i3 = n3 / wm3, j3 = n3 - i3 * wm3, hm3 = ntk3 / wm3;
           const float* tb = la.dtaps + size_t(img3) * ntk3 * 32;
-          float sacc = 0.f;
+          // (branch-free: nine loads in flight, taps outside the map selected to zero; k_depth_update's sum in its order)
+          float tv[9];
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
               const int ii = i3 + dy - 1, jj = j3 + dx - 1;
-              if (ii >= 0 && ii < hm3 && jj >= 0 && jj < wm3) sacc += tb[size_t(ii * wm3 + jj) * 32 + dy * 3 + dx];
+              const bool ok = ii >= 0 && ii < hm3 && jj >= 0 && jj < wm3;
+              const float v = tb[size_t(min(max(ii, 0), hm3 - 1) * wm3 + min(max(jj, 0), wm3 - 1)) * 32 + dy * 3 + dx];
+              tv[dy * 3 + dx] = ok ? v : 0.f;
             }
+          float sacc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) sacc += tv[t];
           sacc += la.dbias[0];
           const float pred = la.d_scale_up ? la.d_eps / (1.0f + expf(-sacc)) : fmaxf(sacc, 0.f) + la.d_eps;
           float x0 = (pred - la.d_min) / (la.d_max - la.d_min);
