@@ -102,6 +102,9 @@ struct Layout {
   float* ubuf;                                          // u = W_m . m_t, fp32 fragment-major (fused seg tails)
   float* tlut;                                          // seg: (Kc + 1, 256) = LUT . W_m^T; bev (<= 8 classes): (2^Kc, 256) = LUT64 . W_m^T
   float* lut64;                                         // bev (<= 8 classes): the 2^Kc x0 vectors of a pixel
+  float* wvs;                                           // depth: W_v0 w_m (256) | W_cat0 w_m (96): the rank-1 terms of the GEMM-free step head
+  float *xproj_f, *rs0, *rvpad;                         // depth chain (inside hbuf, unused by the bf16x3 engine otherwise): xproj fragment-major,
+                                                        // W_cat0 xproj (M, 96), zero-padded map of W_v0 xproj + b_v0; nullptr: does not fit
   unsigned char* tail4_stream;                          // fused tail: conv_seg images + layer 0's 11 projection images
   unsigned char* head7_stream;                          // first step's head from NCHW (k_layer MODE 7): W_m 8 wide + W_x 8 wide + 11
   unsigned char* lt_stream;                             // last layer + tail (k_layer MODE 6): 72 stages of layer L-1 + tail4_stream
@@ -261,6 +264,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     const bool bev_tab = c->task == DDP_TASK_BEV && o->Kc <= 8;
     o->tlut = cv.take(segp ? size_t(o->Kc + 1) * 256 : bev_tab ? (size_t(1) << o->Kc) * 256 : 0);
     o->lut64 = bev_tab ? cv.take((size_t(1) << o->Kc) * 256) : nullptr;
+    o->wvs = c->task == DDP_TASK_DEPTH ? cv.take(512) : nullptr;
   } else {
     o->tail_stream = nullptr;
     o->tail_bias = nullptr;
@@ -273,6 +277,7 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->lt_bias = nullptr;
     o->tlut = nullptr;
     o->lut64 = nullptr;
+    o->wvs = nullptr;
   }
   o->const_bytes = cv.off * sizeof(float);
   // ---- region B: everything that depends on the geometry (batch, r, map size): positional tables, activations
@@ -331,6 +336,16 @@ void carve(const ddp_cfg* c, float* base, Layout* o) {
     o->vpad = nullptr;
     o->vpad_floats = 0;
     o->ubuf = nullptr;
+  }
+  // depth chain: three loop-invariant tensors in the FFN scratch of the fp32 engine (Mp x 1024 floats, idle on the bf16x3 engine)
+  o->xproj_f = o->rs0 = o->rvpad = nullptr;
+  if (o->b3 && c->task == DDP_TASK_DEPTH && o->r == 1) {
+    const size_t need = Mp * 256 + align64(o->M * 96) + o->vpad_floats;
+    if (need <= Mp * DDP_FFN && base) {                 // (a one-row map does not fit: its padded map is 3x the map - the GEMM head stays)
+      o->xproj_f = o->hbuf;
+      o->rs0 = o->hbuf + Mp * 256;
+      o->rvpad = o->rs0 + align64(o->M * 96);
+    }
   }
   o->total = cv.off * sizeof(float);
 }
@@ -422,6 +437,10 @@ int prepare_geometry(const Layout& o, hipStream_t st) {
   // border rows of the padded value maps: zero once, the layer kernel only ever writes the interior
   if (o.b3 && hipMemsetAsync(o.vpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
     set_error("hipMemsetAsync(vpad) failed");
+    return DDP_E_LAUNCH;
+  }
+  if (o.rvpad && hipMemsetAsync(o.rvpad, 0, o.vpad_floats * sizeof(float), st) != hipSuccess) {
+    set_error("hipMemsetAsync(rvpad) failed");
     return DDP_E_LAUNCH;
   }
   return DDP_OK;
@@ -544,6 +563,11 @@ int prepare_model(const ddp_cfg* c, const ddp_weights* w, const Layout& o, hipSt
         return DDP_E_LAUNCH;
       }
     }
+    if (o.wvs) {
+      // depth chain: the rank-1 terms of the GEMM-free step head, W_v0 w_m and W_cat0 w_m (fp32 dot products)
+      DDP_TRY(launch_matvec(w->layers[0].value_proj_w, nullptr, o.wm, o.wvs, 256, 256, 1, 256, 256, 0, 0, st));
+      DDP_TRY(launch_matvec(o.wcat[0], nullptr, o.wm, o.wvs + 256, 256, 96, 1, 256, 96, 0, 0, st));
+    }
     if (o.lut64) {
       // bev u chain: the 2^K x0 vectors of a pixel and their images under W_m (exact fp32 products, as the seg table)
       DDP_TRY(launch_build_bev_lut(w->embedding, o.lut64, o.Kc, c->bit_scale, st));
@@ -577,7 +601,7 @@ int publish_q(const Layout& o, const float* row_major, hipStream_t st) {
 // DetrTransformerEncoder over the fragment-major q (in/out); aff (L,512) = norms.1 affine x FiLM
 // `tail` (seg, u chain): the step's tail is fused into the LAST layer's kernel (k_layer MODE 6) - the caller launches no tail
 int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hipStream_t st, bool l0_projected = false,
-                    bool sb_out = true, const TailLaunch* tail = nullptr) {
+                    bool sb_out = true, const TailLaunch* tail = nullptr, bool depth_chain = false) {
   const int M = int(o.M);
   if (o.b3) {
     // same dataflow on the bf16 matrix cores: q / q1 travel only as SB (operands AND residuals: the three pieces
@@ -642,6 +666,10 @@ int encoder_forward(const ddp_weights* w, const Layout& o, const float* aff, hip
         ll.px = ll.has_next ? o.px[l + 1] : nullptr;
         ll.n_tok = o.Nh;
         ll.w = o.wh;
+        // depth chain: q of the step never exists - layer 0 forms its residual from xproj and the noisy depth (k_layer MODE 10)
+        ll.res_f = (depth_chain && l == 0) ? o.xproj_f : nullptr;
+        ll.wm = o.wm;
+        ll.dvec = o.mask;
         if (tail && l + 1 == o.L) DDP_TRY(launch_b3_layer_tail(ll, *tail, o.lt_stream, o.lt_bias, o.tail_bias, st));
         else DDP_TRY(launch_b3_layer(ll, st));
       } else {
@@ -872,6 +900,32 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
   // T = LUT64 . W_m^T - per step: u update, q = rx + resample(u), layer 0's projections; no GEMM at the map size after u_0.
   const bool lt_other = o.b3 && o.fused_layer && o.fused_pro && o.lt_stream && !(cfg->flags & DDP_FLAG_UNFUSED_TAIL);
   const bool depth_lt = cfg->task == DDP_TASK_DEPTH && lt_other;
+  // depth chain (one noisy map per image, >= 2 layers): the step head without a GEMM.  Loop invariant, once per sample: xproj
+  // fragment-major (layer 0's residual operand), rvpad = W_v0 xproj + b_v0 as a padded map (layer 0's projection kernel run on xproj
+  // itself), rs0 = W_cat0 xproj; per step k_depth_head adds the rank-1 terms in the noisy depth (and runs the previous step's update)
+  const bool depth_chain = depth_lt && o.rvpad && o.L >= 2;
+  if (depth_chain) {
+    DDP_TRY(launch_row_to_blk(o.xproj, o.xproj_f, M0, st));
+    L0ProjLaunch pj;
+    pj.Q = o.xproj_f;
+    pj.stream = o.pro_stream + size_t(8) * 48 * 1024;
+    pj.bias_ext = o.pro_bias;
+    pj.res = nullptr;
+    pj.res_rn = 0;
+    pj.wm = nullptr;
+    pj.dvec = nullptr;
+    pj.upd = nullptr;
+    pj.M = M0;
+    pj.v_out = o.rvpad;
+    pj.samp_out = o.samp;                                  // (the table of a zero depth: overwritten by the first step's head)
+    pj.py = o.py[0];
+    pj.px = o.px[0];
+    pj.n_tok = o.Nh;
+    pj.w = o.wh;
+    DDP_TRY(launch_b3_l0proj(pj, st));
+    DDP_TRY(launch_row_to_sb(o.xproj, 256, o.in_sb, M0, 256, st));
+    DDP_TRY(launch_b3_linear(o.in_sb, o.wp_cat[0], nullptr, nullptr, 0, 0, 0, o.rs0, 96, M0, 96, 256, st, TAG_SAMP));
+  }
   const bool bev_chain = cfg->task == DDP_TASK_BEV && lt_other && o.lut64;
   if (bev_chain) {
     DDP_TRY(launch_bev_resample(o.xproj, o.s, o.B, geom, st));                      // rx = resample(W_x x + b), B maps
@@ -902,7 +956,29 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
     const float* aff = o.aff + size_t(s) * o.L * 512;
     // feat = transform(cat[x, mask_t])
     bool depth_head = false;
-    if (cfg->task == DDP_TASK_DEPTH && o.fused_pro) {
+    if (depth_chain) {
+      DepthHeadArgs ha;
+      ha.rvpad = o.rvpad;
+      ha.rs = o.rs0;
+      ha.wv = o.wvs;
+      ha.ws = o.wvs + 256;
+      ha.py = o.py[0];
+      ha.px = o.px[0];
+      ha.dvec = o.mask;
+      ha.v_out = o.vpad;
+      ha.samp_out = o.samp;
+      ha.R = o.R;
+      ha.h = o.h;
+      ha.w = o.w;
+      DepthUpdateArgs prev;
+      ha.upd = nullptr;
+      if (s > 0) {
+        prev = depth_update_args(steps[s - 1]);
+        ha.upd = &prev;
+      }
+      DDP_TRY(launch_depth_head(ha, st));
+      depth_head = true;
+    } else if (cfg->task == DDP_TASK_DEPTH && o.fused_pro) {
       // down conv over cat[x, depth_t] (depther/ddp.py:236-237) = hoisted x half + ONE depth column: q is formed inside
       // the layer-0 projection kernel (k_layer MODE 3): no feat / SB-conversion / VALUE / SAMP launches
       L0ProjLaunch pj;
@@ -1043,7 +1119,7 @@ int ddp_sample(const ddp_cfg* cfg, const ddp_weights* weights, const ddp_step* s
       tl.x0_idx = bev_chain ? bev_code : nullptr;
       tl.ldl = 32;
     }
-    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !(seg_tail || lt_fused), lt_fused ? &tl : nullptr));
+    DDP_TRY(encoder_forward(weights, o, aff, st, pro_fused || depth_head, !(seg_tail || lt_fused), lt_fused ? &tl : nullptr, depth_chain));
     if (lt_fused && cfg->task == DDP_TASK_BEV) {
       // (probabilities accumulated and the step's x0 codes written by the fused tail; the next step's head updates u from them)
     } else if (seg_tail) {

@@ -166,6 +166,26 @@ int launch_b3_layer(const LayerLaunch& a, hipStream_t st) {
   const int n_cu = cu_count();
   const int tiles = (a.M + b3::LYR_BM - 1) / b3::LYR_BM;
   const int grid = tiles < n_cu ? tiles : n_cu;       // persistent: one block per CU walks tiles blockIdx, +grid, ...
+  if (a.res_f) {
+    // layer 0 of a depth step on the chain path: the residual q = res_f + wm * dvec is formed in the kernel (k_layer MODE 10)
+    if (!a.wm || !a.dvec) {
+      set_error("b3::k_layer (depth layer 0): wm / dvec missing");
+      return DDP_E_NULL;
+    }
+    la.res = a.res_f;
+    la.seg_bias = a.wm;
+    la.dvec = a.dvec;
+    static LdsAttrOnce attr10, attr10_nt;
+    attr10.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN, 10>), int(b3::LYR_LDS_B));
+    attr10_nt.ensure(reinterpret_cast<const void*>(&b3::k_layer<TAG_FC2_LN, 10, 0, true>), int(b3::LYR_LDS_B));
+    prof_begin(TAG_FC2_LN, st);
+    if (a.M >= b3::LYR_NT_MIN_TOKENS)
+      hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN, 10, 0, true>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+    else
+      hipLaunchKernelGGL((b3::k_layer<TAG_FC2_LN, 10>), dim3(grid), dim3(b3::LYR_THREADS), b3::LYR_LDS_B, st, la);
+    prof_end(TAG_FC2_LN, st);
+    return check_launch("b3::k_layer (depth layer 0)");
+  }
   prof_begin(TAG_FC2_LN, st);
   // activation tensors too large to survive in L2 / MALL until the next kernel reads them: non-temporal streams (layer_bf16x3.h)
   if (a.M >= b3::LYR_NT_MIN_TOKENS)

@@ -111,6 +111,11 @@ struct LayerLaunch {
   float* samp_out;
   const float *py, *px;
   int n_tok, w;
+  // layer 0 of a depth step on the chain path (k_layer MODE 10): the residual q = res_f + wm * dvec[m] is formed in the kernel from the
+  // fragment-major xproj (res_f), the concat-conv's depth column (wm, 256) and the noisy depth (dvec); Q is only written.  nullptr: plain.
+  const float* res_f;
+  const float* wm;
+  const float* dvec;
 };
 int launch_b3_layer(const LayerLaunch& a, hipStream_t st);
 // seg tail on the layer kernel's machinery: conv_seg + argmax + softmax accumulation + x0 LUT + DDIM update (SB in / out)
@@ -320,6 +325,21 @@ struct DepthUpdateArgs {
 };
 int launch_depth_update(const DepthUpdateArgs& a, hipStream_t st);
 int launch_mean_r(const float* pred, float* out, int B, int r, int N, hipStream_t st);
+// the depth step head of the chain path WITHOUT a GEMM (ddp_kernels.hip: k_depth_head): layer 0's value map and sample table from their
+// loop-invariant parts + a rank-1 term in the noisy depth, and - upd != nullptr - the previous step's DDIM update in front
+struct DepthHeadArgs {
+  const float* rvpad;       // zero-padded map of W_v (W_x x + b) + b_v, loop invariant (the layout of v_out)
+  const float* rs;          // (M, 96) W_cat (W_x x + b), raw
+  const float* wv;          // (256) W_v w_m
+  const float* ws;          // (96)  W_cat w_m
+  const float *py, *px;     // layer 0's positional tables (bias folded in)
+  float* dvec;              // (M) noisy depth: read; with upd also written
+  float* v_out;
+  float* samp_out;          // head-major [head][M][12]
+  int R, h, w;
+  const DepthUpdateArgs* upd;
+};
+int launch_depth_head(const DepthHeadArgs& a, hipStream_t st);
 // bev
 struct BevGeom {
   int h, w, hh, wh;

@@ -1788,6 +1788,76 @@ __global__ void __launch_bounds__(256) k_depth_update(DepthUpdateArgs a) {
   a.depth_t[m] = a.st.alpha_next * x0 + a.st.sigma_next * eps;
 }
 
+// The depth step head on the chain path, WITHOUT a GEMM.  The concat-conv over cat[x, depth_t] has ONE noisy-map channel
+// (depth/depth/models/depther/ddp.py:236-237), so q = (W_x x + b) + w_m d and - value_proj and the sampling projections being linear -
+//     v_0 = [W_v (W_x x + b) + b_v] + (W_v w_m) d,        s_0 = [W_cat (W_x x + b)] + (W_cat w_m) d + pos
+// with the bracketed terms loop invariant (rvpad, rs: one projection pass per sample) and the rest a rank-1 update per token: every
+// step's head is elementwise.  One wave per token: lane = 4 channels of the value row; lanes 0..15 the 64 sampling offsets (-> pixel
+// coordinates), lanes 16..23 the 32 attention logits (softmax over a head's 4 points: the hardware exp2 / rcp of k_layer's P3 epilogue);
+// the previous step's DDIM update (k_depth_update's arithmetic, scalar per wave) in front when a.upd is set.  q itself is never
+// formed: layer 0 builds its residual from xproj and d (k_layer MODE 10).
+struct DepthHeadDev {
+  const float *rvpad, *rs, *wv, *ws, *py, *px, *taps, *dbias;
+  float *dvec, *v_out, *samp_out;
+  int R, h, w, has_upd, scale_up;
+  float d_min, d_max, d_bit, d_eps, d_sig, d_alpha, d_alpha_next, d_sigma_next;
+};
+__global__ void __launch_bounds__(256) k_depth_head(DepthHeadDev a) {
+  const int lane = threadIdx.x & 63;
+  const int m = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * 4 + int(threadIdx.x >> 6));      // wave-uniform: scalar loads below
+  const int N = a.h * a.w, M = a.R * N;
+  if (m >= M) return;
+  const int img = m / N, n = m - img * N;
+  const int i = n / a.w, j = n - i * a.w;
+  float dv = a.dvec[m];
+  if (a.has_upd) {
+    const float* tb = a.taps + size_t(img) * N * 32;
+    float tv[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ii = i + dy - 1, jj = j + dx - 1;
+        const bool ok = ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
+        const float v = tb[size_t(min(max(ii, 0), a.h - 1) * a.w + min(max(jj, 0), a.w - 1)) * 32 + dy * 3 + dx];
+        tv[dy * 3 + dx] = ok ? v : 0.f;
+      }
+    float sacc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sacc += tv[t];
+    sacc += a.dbias[0];
+    const float pred = a.scale_up ? a.d_eps / (1.0f + expf(-sacc)) : fmaxf(sacc, 0.f) + a.d_eps;
+    float x0 = (pred - a.d_min) / (a.d_max - a.d_min);
+    x0 = (x0 * 2.0f - 1.0f) * a.d_bit;
+    x0 = fminf(fmaxf(x0, -a.d_bit), a.d_bit);
+    const float epsn = a.d_sig * (dv - a.d_alpha * x0);
+    dv = a.d_alpha_next * x0 + a.d_sigma_next * epsn;
+    if (lane == 0) a.dvec[m] = dv;
+  }
+  const size_t vrow = size_t(img) * (a.h + 2) * (a.w + 2) + size_t(i + 1) * (a.w + 2) + (j + 1);
+  const f32x4 rv = *reinterpret_cast<const f32x4*>(a.rvpad + vrow * 256 + lane * 4);
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wv + lane * 4);
+  *reinterpret_cast<f32x4*>(a.v_out + vrow * 256 + lane * 4) = rv + wv * dv;
+  if (lane < 24) {
+    const int col = lane * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.rs + size_t(m) * 96 + col) + *reinterpret_cast<const f32x4*>(a.ws + col) * dv;
+    v += *reinterpret_cast<const f32x4*>(a.py + i * 96 + col) + *reinterpret_cast<const f32x4*>(a.px + j * 96 + col);
+    if (lane < 16) {                       // offsets of head lane / 2, points 2 (lane & 1), + 1 -> pixel coordinates (x, y, x, y)
+      const float fi = float(i), fj = float(j);
+      v[0] += fj; v[1] += fi; v[2] += fj; v[3] += fi;
+      *reinterpret_cast<f32x4*>(a.samp_out + (size_t(lane >> 1) * M + m) * 12 + (lane & 1) * 4) = v;
+    } else {                               // attention weights of head lane - 16: softmax over its 4 points
+      const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_exp2f((v[e] - mx) * 1.44269504088896340736f);
+      const float inv = __builtin_amdgcn_rcpf((v[0] + v[1]) + (v[2] + v[3]));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= inv;
+      *reinterpret_cast<f32x4*>(a.samp_out + (size_t(lane - 16) * M + m) * 12 + 8) = v;
+    }
+  }
+}
+
 __global__ void k_mean_r(const float* __restrict__ pred, float* __restrict__ out, int r, int N, int total) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -2248,6 +2318,27 @@ int launch_feat_depth(const float* xproj, const float* wm, const float* d, float
 int launch_depth_update(const DepthUpdateArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_depth_update, dim3(cdiv(long(a.B_r) * a.h * a.w, 256)), dim3(256), 0, st, a);
   return check_launch("k_depth_update");
+}
+int launch_depth_head(const DepthHeadArgs& a, hipStream_t st) {
+  DepthHeadDev d;
+  d.rvpad = a.rvpad; d.rs = a.rs; d.wv = a.wv; d.ws = a.ws; d.py = a.py; d.px = a.px;
+  d.dvec = a.dvec; d.v_out = a.v_out; d.samp_out = a.samp_out;
+  d.R = a.R; d.h = a.h; d.w = a.w;
+  d.has_upd = a.upd ? 1 : 0;
+  d.taps = nullptr; d.dbias = nullptr; d.scale_up = 0;
+  d.d_min = d.d_max = d.d_bit = d.d_eps = d.d_sig = d.d_alpha = d.d_alpha_next = d.d_sigma_next = 0.f;
+  if (a.upd) {
+    const DepthUpdateArgs& u = *a.upd;
+    if (u.depth_t != a.dvec || u.B_r != a.R || u.h != a.h || u.w != a.w) {
+      set_error("depth head: the fused update must work on the head's own map");
+      return DDP_E_BADCFG;
+    }
+    d.taps = u.taps; d.dbias = u.bias_ptr; d.scale_up = u.scale_up;
+    d.d_min = u.min_depth; d.d_max = u.max_depth; d.d_bit = u.bit_scale; d.d_eps = u.eps_depth;
+    d.d_sig = u.st.sigma; d.d_alpha = u.st.alpha; d.d_alpha_next = u.st.alpha_next; d.d_sigma_next = u.st.sigma_next;
+  }
+  hipLaunchKernelGGL(k_depth_head, dim3(cdiv(long(a.R) * a.h * a.w, 4)), dim3(256), 0, st, d);
+  return check_launch("k_depth_head");
 }
 int launch_mean_r(const float* pred, float* out, int B, int r, int N, hipStream_t st) {
   hipLaunchKernelGGL(k_mean_r, dim3(cdiv(long(B) * N, 256)), dim3(256), 0, st, pred, out, r, N, B * N);

@@ -53,6 +53,9 @@
 //      (bev/mmdet3d/models/fusion_models/ddp.py:290-293: the thresholded maps select one of 2^K mean embeddings).
 //   9  the LAST decoder layer of a depth step + the nine per-tap dot products of the 3x3 conv_depth (token-major rows of 32: column
 //      dy*3+dx; k_depth_update sums the neighbours' taps - depth/depth/models/decode_heads/decode_head.py:264-269).
+//   10 layer 0 of a DEPTH step on the chain path (ddp_api.hip): MODE 0 whose residual is FORMED here - q = xproj + w_m d, the depth
+//      concat-conv with its x half hoisted (depth/depth/models/depther/ddp.py:236-237) - from the fragment-major xproj (la.res) and
+//      the noisy depth (la.dvec); the step head (k_depth_head) wrote only layer 0's value map and sample table, q never exists.
 // Where the cycles of MODE 0 go is measured, not estimated: -DDDP_LYR_STAMP builds + scripts/stamp_layer.py
 // (profiles/r02_layer_cycle_stamps*.json).
 #pragma once
@@ -409,7 +412,7 @@ k_layer(LayerArgs la) {
   int h = lane >> 5;
   const int M = la.M;
   constexpr bool LT = MODE == 6 || MODE == 8 || MODE == 9;      // a whole decoder layer followed by a step tail
-  constexpr bool LYR = MODE == 0 || LT;                          // the decoder layer's phases P0 .. LayerNorm1
+  constexpr bool LYR = MODE == 0 || LT || MODE == 10;            // the decoder layer's phases P0 .. LayerNorm1
   static_assert(!(MODE == 8 || MODE == 9) || NCH == 1, "the bev / depth tails are one 64-row chunk");
   const int ntiles = MODE == 5 ? la.g_tiles : (M + LYR_BM - 1) / LYR_BM;
   if (int(blockIdx.x) >= ntiles) return;
@@ -568,7 +571,7 @@ k_layer(LayerArgs la) {
       for (int i = tid; i < LYR_BIAS_N; i += LYR_THREADS) tab[i] = la.bias_ext[i];
     if constexpr (MODE == 3) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // depth: the concat-conv's depth column
     if constexpr (MODE == 7) tab[LYR_T_BO + tid] = la.bo ? la.bo[tid] : 0.f;      // the concat-conv's bias
-    if constexpr (LT) tab[LYR_T_SEG + tid] = la.seg_bias[tid];
+    if constexpr (LT || MODE == 10) tab[LYR_T_SEG + tid] = la.seg_bias[tid];      // (MODE 10: w_m, the concat-conv's depth column)
     if constexpr (LYR) {
       tab[LYR_T_BO + tid] = la.bo[tid];
       tab[LYR_T_GA0 + tid] = la.ga0[tid];
@@ -1240,17 +1243,35 @@ k_layer(LayerArgs la) {
     // (fp32: 32 x 16 B per lane instead of 48 - the r02i stamps put most of P0's idle time on these two fetches: every CU
     // asks for its residual rows in the same microseconds)
     f32x4 qr[8][4];
+    // MODE 10: the residual is xproj (fragment-major, la.res) + w_m d - formed behind stage 7, where the plain residual is consumed
+    const float* qres = MODE == 10 ? la.res + grp * 8192 + lane * 4 : qf;
+    float dv10 = 0.f;
+    if constexpr (MODE == 10) {
+      int m10 = m_base + j;
+      m10 = m10 < M ? m10 : M - 1;
+      dv10 = la.dvec[m10];
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qf + t * 1024 + g * 256);
+      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qres + t * 1024 + g * 256);
     p0_stage(6, I0, I0);
     DDP_LYR_STAMP_AT(13)                                       // residual fetch (first half) + stage 6
 #pragma unroll
     for (int t = 4; t < 8; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qf + t * 1024 + g * 256);
+      for (int g = 0; g < 4; ++g) qr[t][g] = ld_stream<NT>(qres + t * 1024 + g * 256);
     p0_stage(7, I1, I0);
+    if constexpr (MODE == 10) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 wd = *reinterpret_cast<const f32x4*>(bias_s + LYR_T_SEG + t * 32 + 8 * g + 4 * ht);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qr[t][g][e] = qr[t][g][e] + wd[e] * dv10;       // (the arithmetic of MODE 3's depth head)
+        }
+    }
 
     DDP_LYR_STAMP_AT(0)                                        // P0: output_proj stages
     // ---- P1: y = acc2 + q; x = LayerNorm0(y) -> fc1's B fragments (registers); acc2 <- b2 + x (fc2 bias + residual)
