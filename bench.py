@@ -869,7 +869,7 @@ def main():
                 # the LAST layer of a step runs fused with the step's tail under its own call site (k_layer MODE 6, tag 10): every
                 # launch counted here is a whole layer with the next layer's projections
                 per_tok = full
-                note = f'the {L - 1} launches per step that are followed by another layer; the last layer runs fused with the seg tail'
+                note = f'the {L - 1} launches per step that are followed by another layer; the last layer runs fused with the step tail'
             else:
                 per_tok = (L * (2 * 256 * 256 + 4 * 256 * 1024) + (L - 1) * (2 * 256 * 256 + 2 * 256 * 96)) / L
                 note = 'flops averaged over the L launches of a step'

@@ -88,8 +88,10 @@ if os.path.exists(meta_f):
         out['_meta']['hbm_calibration'] = {
             'kernels': calib, 'write_factor_applied': WF, 'read_factor_measured': RF, 'read_factor_applied': 2.0,
             'note': 'factor = bytes the kernel moved (1 GiB) / (counter KB x 1024), scripts/ubench/hbm_calib.hip under the same rocprofv3 '
-                    'passes on the same box; hbm_write_bytes_per_launch = WRITE_SIZE x write_factor_applied (k_store16_nt: the layer '
-                    "kernels' stream pattern); reads keep the guide's x2 (read_factor_measured beside it)"}
+                    'passes on the same box; hbm_write_bytes_per_launch = WRITE_SIZE x write_factor_applied (k_store16_nt: full 128-B lines, '
+                    "the layer kernels' q' / fragment streams); reads keep the guide's x2 (read_factor_measured beside it).  k_store_row32 "
+                    '(32 B per 1-KiB row per instruction: the padded value map) is COUNTED at ~2.1x its bytes (factor 0.48): a partial-line '
+                    'write costs a whole 64-B burst - that share of a kernel\'s WRITE_SIZE is real DRAM traffic above its algorithmic bytes'}
     cj = os.path.join(src, 'hbm_calib.jsonl')
     if os.path.exists(cj):
         out['_meta']['hbm_stream_rates'] = [json.loads(l) for l in open(cj) if l.startswith('{')]
@@ -124,7 +126,8 @@ for wl in ('ade_swin_t_k3_8x512x1024', 'city_swin_l_k10_4x1024x2048', 'bev_fusio
 f = glob.glob(os.path.join(src, 'prof_fcn', '**', '*kernel_stats.csv'), recursive=True)
 if f:
     shutil.copy(f[0], os.path.join(dst, f'{tag}_fcn_sampler_6_calls_kernel_stats.csv'))
-for name in ('power_components.json', 'fcn_calls.log'):
+for name in ('power_components.json', 'fcn_calls.log', 'call_times_bev.jsonl', 'call_times_kitti.jsonl', 'gather_by_position_init.json',
+             'gather_by_position_trained.json', 'hbm_calib.jsonl', 'bench_bev_fusion_k3_r4_2x200x200.json'):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f'{tag}_{name}'))

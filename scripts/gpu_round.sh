@@ -24,7 +24,9 @@ cut -c1-2500 $OUT/bench.json; tail -3 $OUT/bench.err
 python bench.py --workload ade_swin_t_k3_1x512x1024 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_ade_swin_t_k3_1x512x1024.json 2> $OUT/bench_b1.err
 cut -c1-400 $OUT/bench_ade_swin_t_k3_1x512x1024.json
 REPO=$PWD
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power"
+# (--no-trained-like: the default line also times an engine with the trained_like weight profile, whose gather launches - same kernel
+# name, 0.23 instead of 0.15 ms - were averaged into the init profile's kernel stats until round 5: the "bimodal" 0.145 - 0.292 ms)
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power --no-trained-like"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -o ddp -- $BENCH > $REPO/$OUT/prof_run.log 2>&1
 # the rows either side of the loop (FPN, MultiStageMerging, post-loop epilogue) in their own kernel-stats pass
@@ -42,6 +44,10 @@ $CAL > $REPO/$OUT/hbm_calib.jsonl 2> $REPO/$OUT/hbm_calib.err
 timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_calib_wr -o cal -- $CAL > $REPO/$OUT/pmc_calib_wr.log 2>&1
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/$OUT/pmc_calib_rd -o cal -- $CAL > $REPO/$OUT/pmc_calib_rd.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_ade_swin_t_k3_1x512x1024 -o ddp -- python $REPO/bench.py --workload ade_swin_t_k3_1x512x1024 --steps 20 --warmup 2 --no-cpu-baseline --no-roofline --no-power > $REPO/$OUT/prof_b1.log 2>&1
+# the gather by position in the step, init and trained_like weight profiles (scripts/gather_by_position.py on kernel traces)
+python $REPO/scripts/gather_by_position.py $(find $REPO/$OUT/prof -name '*kernel_trace.csv' | head -1) > $REPO/$OUT/gather_by_position_init.json 2>/dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_trained -o ddp -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-power --weights trained_like > $REPO/$OUT/prof_trained.log 2>&1
+python $REPO/scripts/gather_by_position.py $(find $REPO/$OUT/prof_trained -name '*kernel_trace.csv' | head -1) > $REPO/$OUT/gather_by_position_trained.json 2>/dev/null
 # the other BASELINE configurations (per-GPU shards): kernel stats + MFMA-busy counters each
 WLS="city_swin_l_k10_4x1024x2048 kitti_depth_k20_16x352x1216 bev_fusion_k3_8x200x200"
 [ "$QUICK" = quick ] && WLS=
@@ -56,6 +62,24 @@ for wl in $WLS; do
   timeout 400 python bench.py --workload $wl --steps 3 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   tail -1 $OUT/bench_$wl.json | cut -c1-200
 done
+# round 6: the fused step boundaries of the depth / BEV samplers against the round-5 launches (DDP_TAIL_FUSED=0), per-call HIP-event
+# times in ONE process with power and clock beside them; the shipped BEV randsteps = 4 setting as a bench line
+if [ "$QUICK" != quick ]; then
+  timeout 400 python scripts/call_times.py --workload bev_fusion_k3_8x200x200 fused= unfused=DDP_TAIL_FUSED=0 --calls 30 --blocks 2 > $OUT/call_times_bev.jsonl 2> $OUT/call_times_bev.err
+  timeout 400 python scripts/call_times.py --workload kitti_depth_k20_16x352x1216 fused= unfused=DDP_TAIL_FUSED=0 --calls 6 --blocks 2 > $OUT/call_times_kitti.jsonl 2> $OUT/call_times_kitti.err
+  timeout 300 python bench.py --workload bev_fusion_k3_r4_2x200x200 --steps 5 --warmup 1 > $OUT/bench_bev_fusion_k3_r4_2x200x200.json 2> $OUT/bench_bev_r4.err
+  python - $OUT <<'PY'
+import json, sys
+for wl in ('bev', 'kitti'):
+    try:
+        rows = [json.loads(l) for l in open(f'{sys.argv[1]}/call_times_{wl}.jsonl') if l.startswith('{"variant"')]
+        for v in ('fused', 'unfused'):
+            ms = [r['median_ms'] for r in rows if r['variant'] == v]
+            print(wl, v, 'median ms per call', ms)
+    except Exception as e:
+        print(wl, e)
+PY
+fi
 # the process-group path of bench.py (RCCL init, 34 MB weight broadcast, replica check by all_gather, barrier, MAX all_reduce)
 # under the launcher at world size 1 - the multi-GPU code path with the one device this box has
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py \
