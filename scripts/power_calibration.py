@@ -9,11 +9,10 @@ idle issue slots.)  One process, one box, every leg with package power and shade
   3. scripts/ubench/mfma_chip: v_mfma_f32_32x32x16_bf16 back to back on every SIMD of the chip, no memory at all - the
      ceiling of the matrix pipes under the cap - with zero and with random operands, one and two waves per SIMD, and with
      the LDS fragment reads and VALU fillers that surround the layer kernel's MFMAs;
-  4. (--sweep) the headline loop with the package power cap lowered (amdsmi_set_power_cap) and with the shader clock
-     limited (amdsmi_set_gpu_clk_limit), each restored afterwards: throughput against watts and against MHz.  Skipped with a
-     note when the container may not change them.
+(A power-cap / clock-limit sweep existed until round 5; the pool runs every job at the machine's default settings - no setter of any
+kind is called from this repository - so it is gone.  Everything here only READS power and clock.)
 
-Prints one JSON object; `gpurun -- 'python scripts/power_calibration.py --sweep > gpurun_out/<tag>/power_calibration.json'`."""
+Prints one JSON object; `gpurun -- 'python scripts/power_calibration.py > gpurun_out/<tag>/power_calibration.json'`."""
 import argparse
 import json
 import os
@@ -96,53 +95,15 @@ def mfma_chip(wps, chains, pattern, seconds, ldsr=0, valu=0, dma=0, hbm=0, share
     return rec
 
 
-class Smi:
-    def __init__(self):
-        sys.path.insert(0, '/opt/rocm/share/amd_smi')
-        import amdsmi
-        amdsmi.amdsmi_init()
-        self.smi = amdsmi
-        self.h = amdsmi.amdsmi_get_processor_handles()[0]
-
-    def cap_info(self):
-        return {k: int(v) for k, v in self.smi.amdsmi_get_power_cap_info(self.h).items() if isinstance(v, (int, float))}
-
-    def set_cap_w(self, watts):
-        info = self.cap_info()
-        unit = 1_000_000 if info.get('power_cap', 0) > 100_000 else 1
-        self.smi.amdsmi_set_power_cap(self.h, 0, int(watts * unit))
-
-    def default_cap_w(self):
-        info = self.cap_info()
-        unit = 1_000_000 if info.get('power_cap', 0) > 100_000 else 1
-        return (info.get('default_power_cap') or info.get('power_cap')) / unit
-
-    def sclk_max_default(self):
-        try:
-            f = self.smi.amdsmi_get_clk_freq(self.h, self.smi.AmdSmiClkType.SYS)
-            return int(max(f['frequency']) / 1e6)
-        except Exception:
-            return 2400
-
-    def set_sclk_max(self, mhz):
-        self.smi.amdsmi_set_gpu_clk_limit(self.h, 'sclk', 'max', int(mhz))
-
-    def auto(self):
-        self.smi.amdsmi_set_gpu_perf_level(self.h, self.smi.AmdSmiDevPerfLevel.AUTO)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=3.0)
-    ap.add_argument('--sweep', action='store_true')
     ap.add_argument('--components', action='store_true',
                     help='only the attribution table of VERDICT r03 next #4: the layer kernel, then the MFMA + LDS-read + VALU mix alone, '
                          '+ the LDS-DMA weight stream, + the HBM fragment streams (one box, one process, watts and MHz beside each)')
     ap.add_argument('--operand-sharing', action='store_true',
                     help='only VERDICT r04 next #6 (i): nJ per MFMA when consecutive MFMAs share their A / their B / both operands '
                          '(scripts/ubench/mfma_chip.hip, registers only)')
-    ap.add_argument('--caps', default='1200,1000', help='package power caps (W) for the sweep')
-    ap.add_argument('--clocks', default='1500', help='shader clock limits (MHz) for the sweep')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     wl = bench.WORKLOADS['ade_swin_t_k3_8x512x1024']
@@ -194,51 +155,6 @@ def main():
     print('mfma_chip', json.dumps(res['mfma_chip']), file=sys.stderr, flush=True)
     print('mfma_chip_with_fillers', json.dumps(res['mfma_chip_with_fillers']), file=sys.stderr, flush=True)
     res['headline_after'] = headline(eng, dx, dn, out, wl['batch'], args.seconds)
-    if args.sweep:
-        sweep = {'power_cap': [], 'sclk_max': []}
-        try:
-            smi = Smi()
-            default_w = smi.default_cap_w()
-            default_mhz = smi.sclk_max_default()
-            sweep['sclk_max_default_mhz'] = default_mhz
-            sweep['cap_info'] = smi.cap_info()
-            try:
-                for cap in [float(c) for c in args.caps.split(',') if c]:
-                    smi.set_cap_w(cap)
-                    time.sleep(0.5)
-                    rec = headline(eng, dx, dn, out, wl['batch'], args.seconds)
-                    rec['cap_set_w'] = cap
-                    sweep['power_cap'].append(rec)
-                    print('cap', json.dumps(rec), file=sys.stderr, flush=True)
-            except Exception as e:
-                sweep['power_cap_error'] = f'{type(e).__name__}: {e}'
-            finally:
-                try:
-                    smi.set_cap_w(default_w)
-                except Exception as e:
-                    sweep['power_cap_restore_error'] = f'{type(e).__name__}: {e}'
-            try:
-                for mhz in [int(c) for c in args.clocks.split(',') if c]:
-                    smi.set_sclk_max(mhz)
-                    time.sleep(0.5)
-                    rec = headline(eng, dx, dn, out, wl['batch'], args.seconds)
-                    rec['sclk_max_set_mhz'] = mhz
-                    sweep['sclk_max'].append(rec)
-                    print('clk', json.dumps(rec), file=sys.stderr, flush=True)
-            except Exception as e:
-                sweep['sclk_max_error'] = f'{type(e).__name__}: {e}'
-            finally:
-                for restore in (lambda: smi.set_sclk_max(default_mhz), smi.auto):
-                    try:
-                        restore()
-                    except Exception as e:
-                        sweep.setdefault('sclk_restore_notes', []).append(f'{type(e).__name__}: {e}')
-            time.sleep(0.5)
-            sweep['cap_info_after'] = smi.cap_info()
-            sweep['headline_restored'] = headline(eng, dx, dn, out, wl['batch'], args.seconds)
-        except Exception as e:
-            sweep['error'] = f'{type(e).__name__}: {e}'
-        res['sweep'] = sweep
     print(json.dumps(res))
 
 
