@@ -1649,7 +1649,7 @@ static int msm_layout(int batch, const int* lh, const int* lw, char* wbase, char
     o->a[l] = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
     o->y[l] = reinterpret_cast<float*>(take(Mp * 256 * sizeof(float)));
   }
-  const size_t chunks = (size_t(lh[0]) * lw[0] + 255) / 256;
+  const size_t chunks = (size_t(lh[0]) * lw[0] + 31) / 32;   // (32-token chunks: the merging kernel writes the statistics itself)
   o->partial = reinterpret_cast<double*>(take(size_t(batch) * chunks * 64 * sizeof(double)));
   o->stats = reinterpret_cast<float*>(take(size_t(batch) * 64 * sizeof(float)));
   o->abytes = off;
@@ -1695,8 +1695,9 @@ int msm_core(const float* const* a_blk, const int* level_h, const int* level_w, 
   }
   DDP_TRY(launch_b3_sgemm(pr, 4, 0, 0, st));               // all four levels in one persistent launch
   const float* yl[3] = {o.y[1], o.y[2], o.y[3]};
-  DDP_TRY(launch_msm_sum_blk(o.y[0], yl, level_h + 1, level_w + 1, batch, level_h[0], level_w[0], align_corners ? 1 : 0, st));
-  DDP_TRY(launch_gn_stats_blk(o.y[0], o.partial, o.stats, batch, N, 1e-5f, st));
+  DDP_TRY(launch_msm_sum_blk(o.y[0], yl, level_h + 1, level_w + 1, batch, level_h[0], level_w[0], align_corners ? 1 : 0, st, o.partial));
+  if (N % 32 == 0) DDP_TRY(launch_gn_final32(o.partial, o.stats, batch, N, 1e-5f, st));      // (statistics fused into the merging kernel)
+  else DDP_TRY(launch_gn_stats_blk(o.y[0], o.partial, o.stats, batch, N, 1e-5f, st));
   return launch_gn_apply_nchw_blk(o.y[0], o.stats, d_gn_w, d_gn_b, d_out, batch, N, st);
 }
 }  // namespace
@@ -1842,9 +1843,18 @@ int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, f
   }
   DDP_TRY(launch_b3_sgemm(pr, 4, 0, 0, st));
   // GroupNorm + top-down path (:173-185): lat_l = GN(y_l) + nearest_up(lat_{l+1}), coarsest level first, one kernel per level
+  // (the statistics of all four levels are finalised by ONE launch when the GEMM epilogue wrote every level's partial sums)
+  bool all32 = true;
+  int Nl[4];
+  for (int l = 0; l < 4; ++l) {
+    Nl[l] = levels[l].h * levels[l].w;
+    all32 = all32 && Nl[l] % 32 == 0;
+  }
+  if (all32) DDP_TRY(launch_gn_final32_multi(o.partial, o.stats, Nl, 4, batch, 1e-5f, st));
   for (int l = 3; l >= 0; --l) {
     const ddp_fpn_level& v = levels[l];
-    if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    if (all32) {
+    } else if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
     else DDP_TRY(launch_gn_stats_blk(o.y[l], o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
     DDP_TRY(launch_gn_apply_add_blk(o.y[l], o.stats[l], v.lat_gn_w, v.lat_gn_b, l < 3 ? o.lat[l + 1] : nullptr, o.lat[l], batch, v.h,
                                     v.w, l < 3 ? levels[l + 1].h : 1, l < 3 ? levels[l + 1].w : 1, st));
@@ -1865,9 +1875,11 @@ int fpn_core(const ddp_fpn_level* levels, int batch, const float* const* d_in, f
     pr[l].gn_partial = (v.h * v.w) % 32 == 0 ? o.partial[l] : nullptr;
   }
   DDP_TRY(launch_b3_sgemm(pr, 4, 0, 1, st));
+  if (all32) DDP_TRY(launch_gn_final32_multi(o.partial, o.stats, Nl, 4, batch, 1e-5f, st));
   for (int l = 0; l < 4; ++l) {
     const ddp_fpn_level& v = levels[l];
-    if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
+    if (all32) {
+    } else if ((v.h * v.w) % 32 == 0) DDP_TRY(launch_gn_final32(o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
     else DDP_TRY(launch_gn_stats_blk(o.y[l], o.partial[l], o.stats[l], batch, v.h * v.w, 1e-5f, st));
     if (d_out) DDP_TRY(launch_gn_apply_nchw_blk(o.y[l], o.stats[l], v.out_gn_w, v.out_gn_b, d_out[l], batch, v.h * v.w, st));
     else       // (the laterals are dead once the convolution has run: their buffers take the normalised outputs)

@@ -300,7 +300,11 @@ int launch_gn_apply_add_blk(const float* y_blk, const float* stats, const float*
                             float* out_blk, int B, int hf, int wf, int hc, int wc, hipStream_t st);
 int launch_gn_apply_nchw_blk(const float* y_blk, const float* stats, const float* gamma, const float* beta, float* out, int B, int N,
                              hipStream_t st);
-int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st);
+// gn_partial (optional, used when h * w % 32 == 0): the merged map's GroupNorm partial sums in k_gn_final32's format, fused
+int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st,
+                       double* gn_partial = nullptr);
+// launch_gn_final32 for up to four maps (N[l] % 32 == 0 each) in one launch
+int launch_gn_final32_multi(const double* const* partial, float* const* stats, const int* N, int n_maps, int B, float eps, hipStream_t st);
 // 3x3 convolution as an implicit GEMM (FCNHeadWithTime, FPN: launch_b3_sgemm with conv_h > 0): weights packed tap-major
 int launch_pack_conv3x3_scaled(const float* w, const float* scale, float* out, int cout, int cin, hipStream_t st);
 int launch_fcn_fold(const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps,

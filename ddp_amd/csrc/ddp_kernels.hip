@@ -1387,6 +1387,8 @@ struct MsmSumArgs {
   const float* yl[3];       // levels 1..3 conv outputs at their own resolution, blk
   int lh[3], lw[3];
   int h, w, rows, align;
+  double* gn_partial;       // optional (h * w % 32 == 0): GroupNorm partial sums of the merged map, [image][token / 32][group] {sum, sum of
+                            // squares} - the format k_gn_final32 reduces; a wave = 32 tokens x the 8 channels of ONE group
 };
 __global__ void __launch_bounds__(256) k_msm_sum_blk(MsmSumArgs a) {
   const long idx = long(blockIdx.x) * 256 + threadIdx.x;
@@ -1411,6 +1413,63 @@ __global__ void __launch_bounds__(256) k_msm_sum_blk(MsmSumArgs a) {
     for (int e = 0; e < 4; ++e) acc[e] += bilerp(v00[e], v01[e], v10[e], v11[e], y, x);
   }
   *reinterpret_cast<f32x4*>(a.y0 + off) = acc;
+  if (a.gn_partial) {
+    // fused statistics (round 6: the separate pass over the merged map - k_gn_partial - is gone): this wave holds pieces 2k, 2k + 1
+    // = channels 8k .. 8k + 7 = group k of its 32 tokens (rows % 32 == 0: no lane returned above); fp64, fixed butterfly order
+    double sv = 0.0, qv = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sv += double(acc[e]);
+      qv += double(acc[e]) * double(acc[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sv += __shfl_xor(sv, o, 64);
+      qv += __shfl_xor(qv, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      double* dst = a.gn_partial + ((size_t(b) * (N >> 5) + (n >> 5)) * 32 + (p >> 1)) * 2;
+      dst[0] = sv;
+      dst[1] = qv;
+    }
+  }
+}
+
+// k_gn_final32 for up to four maps in ONE launch (grid.y = map): the FPN finalises the statistics of its four levels together
+struct GnFinalMulti {
+  const double* partial[4];
+  float* stats[4];
+  int N[4];
+};
+__global__ void __launch_bounds__(1024) k_gn_final32_multi(GnFinalMulti a, float eps) {
+  __shared__ double red[32][32][2];
+  const int lv = blockIdx.y;
+  const double* partial = a.partial[lv];
+  float* stats = a.stats[lv];
+  const int N = a.N[lv], chunks = N / 32;
+  const int b = blockIdx.x, g = threadIdx.x & 31, part = threadIdx.x >> 5;
+  double s = 0.0, q = 0.0;
+  for (int ck = part; ck < chunks; ck += 32) {
+    const double* p = partial + ((size_t(b) * chunks + ck) * 32 + g) * 2;
+    s += p[0];
+    q += p[1];
+  }
+  red[part][g][0] = s;
+  red[part][g][1] = q;
+  __syncthreads();
+  if (part == 0) {
+    double ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      ts += red[k][g][0];
+      tq += red[k][g][1];
+    }
+    const double cnt = double(N) * 8.0;
+    const double mean = ts / cnt;
+    const double var = fmax(tq / cnt - mean * mean, 0.0);
+    stats[(b * 32 + g) * 2] = float(mean);
+    stats[(b * 32 + g) * 2 + 1] = float(1.0 / sqrt(var + double(eps)));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2227,8 +2286,20 @@ int launch_gn_apply_nchw_blk(const float* y_blk, const float* stats, const float
   hipLaunchKernelGGL(k_gn_apply_nchw<true>, dim3(cdiv(N, 64), 4, B), dim3(256), 0, st, y_blk, stats, gamma, beta, out, N);
   return check_launch("k_gn_apply_nchw<blk>");
 }
-int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st) {
+int launch_gn_final32_multi(const double* const* partial, float* const* stats, const int* N, int n_maps, int B, float eps, hipStream_t st) {
+  GnFinalMulti a;
+  for (int l = 0; l < 4; ++l) {
+    a.partial[l] = l < n_maps ? partial[l] : nullptr;
+    a.stats[l] = l < n_maps ? stats[l] : nullptr;
+    a.N[l] = l < n_maps ? N[l] : 32;
+  }
+  hipLaunchKernelGGL(k_gn_final32_multi, dim3(B, n_maps), dim3(1024), 0, st, a, eps);
+  return check_launch("k_gn_final32_multi");
+}
+int launch_msm_sum_blk(float* y0, const float* const* yl, const int* lh, const int* lw, int B, int h, int w, int align, hipStream_t st,
+                       double* gn_partial) {
   MsmSumArgs a;
+  a.gn_partial = (h * w) % 32 == 0 ? gn_partial : nullptr;
   a.y0 = y0;
   for (int l = 0; l < 3; ++l) {
     a.yl[l] = yl[l];
