@@ -232,6 +232,20 @@ def test_segmentor_batched_harness():
     mixed, a, b = run([m0, m1]), run([m0, m0]), run([m1, m1])
     assert mixed[0].shape == (H + 5, W + 3) and mixed[1].shape == (H - 7, W + 9)
     assert np.array_equal(mixed[0], a[0]) and np.array_equal(mixed[1], b[1])
+    # ... and every image of the mixed call against the ORACLE (the harness test was self-consistency only): the
+    # reference's sampler (b = 1, its own noise: the draw the batched call made for that image) + the reference's op sequence of
+    # simple_test for that image's meta (crop to img_shape, resize to ori_shape, softmax, flip undone, argmax - encoder_decoder.py:236-296)
+    from oracle import ddp_oracle as O
+    torch.manual_seed(3)
+    nb = torch.randn((2, cfg['randsteps'], 256, cfg['h'], cfg['w']), device='cuda').cpu()
+    for i, (xi, meta) in enumerate(((x, m0), (x.flip(dims=(3,)), m1))):
+        sc = O.ddim_sample_seg(xi, nb[i], sd, timesteps=cfg['timesteps'], randsteps=cfg['randsteps'], bit_scale=cfg['bit_scale'],
+                               accumulation=cfg['accumulation'])
+        ref = O.seg_postprocess(sc, (H, W), meta['img_shape'][:2], meta['ori_shape'][:2], False,
+                                meta.get('flip_direction') if meta['flip'] else None)[0]
+        agree = float((torch.from_numpy(mixed[i].astype('int64')) == ref).float().mean())
+        print(f'batched harness, image {i}: class map agreement with the oracle {agree:.5f}')
+        assert agree >= 0.999
     torch.manual_seed(3)
     fwd = model([img], [[m0, m1]], return_loss=False, rescale=True)
     assert all(np.array_equal(p, q) for p, q in zip(fwd, mixed))
