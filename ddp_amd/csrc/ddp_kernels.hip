@@ -1991,7 +1991,8 @@ __global__ void __launch_bounds__(256) k_bev_resample(const float* __restrict__ 
 // q[(b r + ri) Nh + n] (fragment-major) = rx[b Nh + n] (row-major, shared by the r replicas) + resample(u[(b r + ri)])[n]
 // One block = one 32-token group of the fragment-major q: each of its 4 waves forms 8 tokens' rows (a row = 64 lanes x 16 B: the four
 // corner rows of u and the row of rx are coalesced 1-KiB loads), the rows meet in LDS and leave in fragment order - 8 coalesced 1-KiB
-// stores per wave instead of 64 scattered 16-B pieces per token (0.285 -> ms per launch at C5, profiles/r06*).
+// stores per wave instead of 64 scattered 16-B pieces per token.  (What made this kernel slow was neither the store pattern nor the
+// block order - 0.285 / 0.298 ms with either - but the conditional corner loads: bev_bilinear_row above, 0.18 ms; profiles/r06c, r06d.)
 __global__ void __launch_bounds__(256) k_bev_q(const float* __restrict__ u, const float* __restrict__ rx, float* __restrict__ q_blk, int R,
                                                 int r, BevGeom g) {
   __shared__ __attribute__((aligned(16))) float tile[32][260];        // +4 floats per row: the fragment-order reads spread over the banks
@@ -2001,7 +2002,7 @@ __global__ void __launch_bounds__(256) k_bev_q(const float* __restrict__ u, cons
   // XCD-aware order: workgroups go round-robin over the 8 XCDs (each with its own 4-MiB L2), so block b lands on XCD b % 8.  Group
   // gid = (b % 8) * ceil(groups / 8) + b / 8 gives every XCD ONE contiguous eighth of the token range (one map at R = 8): the u rows
   // neighbouring tokens share (each is a corner of ~2.4 x 4 tokens) are hits in that XCD's L2 instead of eight XCDs each pulling every
-  // row through the fabric (r06c: 0.29 ms = 2.7 TB/s on the algorithmic 0.79 GB with raster order).
+  // row through the fabric.  (Kept as the placement that bounds the fabric traffic; by itself it did not move the kernel's time - r06c.)
   const int groups = (M + 31) / 32, per = (groups + 7) / 8;
   const int gid = int(blockIdx.x & 7) * per + int(blockIdx.x >> 3);
   if (gid >= groups || int(blockIdx.x >> 3) >= per) return;

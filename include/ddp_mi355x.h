@@ -79,8 +79,13 @@ enum { DDP_FLAG_UNFUSED_LAYER = 1, DDP_FLAG_UNFUSED_PROLOGUE = 2, DDP_FLAG_RECOR
        DDP_FLAG_SB_HEAD = 128 /* the first step's head as the four launches it was fused from (NCHW -> split fragments of x and of
                                   the start noise, the x-projection GEMM, k_layer MODE 2) instead of ONE kernel that reads the
                                   caller's NCHW tensors directly (k_layer MODE 7); A/B runs and parity tests of the separate kernels */,
-       DDP_FLAG_UNFUSED_TAIL = 64 /* the last decoder layer of a step and the step's seg tail as the two kernels they were fused
-                                     from (identical arithmetic; same-box A/B runs, parity tests of the separate kernels) */ };
+       DDP_FLAG_UNFUSED_TAIL = 64 /* the step boundary as the launches it was fused from (same-box A/B runs, parity tests of the separate
+                                     kernels).  seg: the last decoder layer of a step and the step's tail as two kernels (k_layer MODE 0 +
+                                     MODE 4 / 1 instead of MODE 6; identical arithmetic, bit-identical results).  depth: the GEMM step
+                                     head (k_layer MODE 3), the 9-tap head GEMM on the SB layer output and k_depth_update per step instead
+                                     of k_depth_head + k_layer MODE 10 / MODE 9.  bev: the concat-conv GEMM, grid resampling, head GEMM and
+                                     k_bev_update on the 256-channel map per step instead of the u chain (k_bev_u_update, k_bev_q, k_layer
+                                     MODE 8).  depth / bev: the same operators regrouped - results agree to rounding, not bit for bit */ };
 
 /* Problem description.  Mirrors the constructor kwargs of the reference `DDP` classes
  * (segmentors/ddp.py:57-67; depther/ddp.py:42-54; fusion_models/ddp.py:67-80). */

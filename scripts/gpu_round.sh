@@ -9,6 +9,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "from ddp_amd import build; print(build.source_hash())" > $OUT/source_sha.txt
+# the micro-benchmark binaries are git-ignored build products: a fresh container does not have them
+for u in mfma_chip hbm_calib; do
+  [ -x scripts/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench/$u.hip -o scripts/ubench/$u > $OUT/ubench_build_$u.log 2>&1
+done
 # -s: the full-size parity tests and the bf16x3 arithmetic tests print the figures DESIGN.md quotes
 if [ "$QUICK" = quick ]; then
   KSEL='-k not(c3_cityscapes or c4_kitti or c5_bev)'
