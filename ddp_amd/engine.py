@@ -148,7 +148,8 @@ class DDPEngine:
             fused_layer = os.environ.get('DDP_LAYER_FUSED', '1') != '0'
         if fused_prologue is None:
             fused_prologue = os.environ.get('DDP_PROLOGUE_FUSED', '1') != '0'
-        if fused_tail is None:     # DDP_TAIL_FUSED=0: the last layer of a step and the seg tail as two kernels (A/B runs, tests)
+        if fused_tail is None:     # DDP_TAIL_FUSED=0: the step boundary as the launches it was fused from (DDP_FLAG_UNFUSED_TAIL: seg - the last
+                                   # layer and the tail as two kernels; depth / bev - the round-5 GEMM heads and update kernels; A/B runs, tests)
             fused_tail = os.environ.get('DDP_TAIL_FUSED', '1') != '0'
         if nchw_head is None:      # DDP_NCHW_HEAD=0: the first step's head through the SB conversions + x-projection GEMM + MODE 2
             nchw_head = os.environ.get('DDP_NCHW_HEAD', '1') != '0'
