@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(64 * GSB_WAVES) k_msda_gather_sb(const float* 
 // GL_TH x GL_TW tile of tokens of one map and ONE head: it stages that head's 128-B slice of the value map for the
 // tile plus a halo into LDS by LDS-DMA (one 1-KiB instruction = 8 pixels x 128 B, coalesced), then serves the 16 bilinear
 // taps of every token from LDS (ds_read_b128, the four corners as immediate offsets of one address).  Fill traffic is
-// (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.7 x 128 B per (token, head) instead of 2 KiB, and - heads pinned to XCDs, see the
-// kernel - the 1.7 x that is halo comes out of L2, not HBM.
+// (GL_WW x GL_WH) / (GL_TH x GL_TW) = 2.4 x 128 B per (token, head) instead of 2 KiB, and - heads pinned to XCDs, see the
+// kernel - the 1.4 x that is halo comes out of L2, not HBM.
 //   * The window of a head is centred on the tile's mean sampling offset of that head: the reference initialises the
 //     offsets as a ring of radius 1..4 px per head (multi_scale_deform_attn.py:233-244), so the points of a head spread
 //     +-1.5 px around their mean and GL_HALO = 3 leaves 1.5 px for the learned, content-dependent part.  The fill starts
@@ -351,12 +351,21 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
 constexpr int GL_THREADS = 512;
 // tile GL_TH x GL_TW tokens (128 per block: 8 waves x 2 runs of 8 x-adjacent tokens), halo GL_HALO:
-//   window width  GL_WW = TW + 2 HALO + 1: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1 corner
+//   window width  GL_WW = TW + 2 HALO + 1 - GL_TRIM.  TRIM = 0: floor(x) in [x0 + mean - HALO, x0 + TW - 1 + mean + HALO] and its +1
+//   corner.  TRIM = 1 (the product): the +1 corner comes out of the HIGH-side halo - floor(x) - (x0 + mean) in [-HALO, TW - 2 + HALO].
+//   floor() already biases the corner index downward (a point 1.5 px above the mean has its top-left corner 1 px above it), so the
+//   lost column / row is the one used least, and 22 x 14 px = 39 936 B + 64 B is exactly a QUARTER of the CU's 160 KiB: four blocks per
+//   CU instead of three, at 47 registers (the compiler budgets for the occupancy the LDS size allows).  Same box, ms per launch, init /
+//   trained_like profile / Cityscapes size: TRIM 0 0.154 / 0.237 / 0.310, **TRIM 1 0.143 / 0.219 / 0.289**, TRIM 2 0.149 / 0.226,
+//   TRIM 3 0.163 / 0.232 (profiles/r06g_*, r06h_*; bit-identical outputs: which memory serves a tap never changes its value).
+#ifndef DDP_GL_TRIM
+#define DDP_GL_TRIM 1
+#endif
 template <int TH, int TW, int HALO, int NT = GL_THREADS>
 struct GlGeom {
   static constexpr int TOK = TH * TW, NW = NT / 64, NG = TOK / (8 * NW);   // NG runs of 8 x-adjacent tokens per wave
   static_assert(TW % 8 == 0 && NG * 8 * NW == TOK && TOK % (NT / 4) == 0, "rows of whole 8-token runs, whole runs per wave");
-  static constexpr int WW = TW + 2 * HALO + 1, WH = TH + 2 * HALO + 1;
+  static constexpr int WW = TW + 2 * HALO + 1 - DDP_GL_TRIM, WH = TH + 2 * HALO + 1 - DDP_GL_TRIM;
   static constexpr int PIX = WW * WH;               // window pixels x 128 B
   static constexpr int DMA = (PIX + 7) / 8;         // LDS-DMA instructions of 8 pixels (1 KiB)
   static constexpr int WIN_B = DMA * 1024;
@@ -387,7 +396,8 @@ __device__ __forceinline__ void gl_dma(const float* gbase, unsigned byte_off, un
 #ifndef DDP_GL_V
 #define DDP_GL_V 2
 #endif
-// window halo of the product launch (launch_msda_gather_sb_pad): 3 -> 23 x 15 px = 44 KiB, three blocks per CU.  Round 5, same
+// window halo of the product launch (launch_msda_gather_sb_pad): 3, trimmed -> 22 x 14 px = 39 KiB, four blocks per CU (until round 5:
+// 23 x 15 px = 44 KiB, three blocks - the figures below were measured in that form).  Round 5, same
 // box (profiles/r05c_ab_gather_*.txt; ms per launch at C2, init / trained_like weight profile): halo 3 0.151 / 0.230; halo 5
 // (64 KiB, two blocks per CU) 0.200 / 0.274; halo 6 (77 KiB) 0.209 / 0.254 - with content-dependent offsets of +- 2.4 px
 // nearly every 8-token group has SOME corner outside even a +-6 px window, so a larger window only costs occupancy.  The mixed
@@ -2218,7 +2228,7 @@ int launch_msda_gather_sb_pad(const float* vpad, const float* samp, unsigned sho
 #define DDP_GL_TH 8
 #define DDP_GL_TW 16
 #define DDP_GL_NT GL_THREADS
-#define DDP_GL_MINW (DDP_GL_HALO <= 3 ? 6 : 4)
+#define DDP_GL_MINW (DDP_GL_HALO <= 3 ? (DDP_GL_TRIM >= 1 ? 8 : 6) : 4)
 #endif
   constexpr int TH = DDP_GL_TH, TW = DDP_GL_TW, NT = DDP_GL_NT;
   const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
