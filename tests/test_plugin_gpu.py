@@ -320,7 +320,8 @@ def test_segmentor_size_stream_b1():
     assert not torch.equal(out2, outb[:1])
 
 
-@pytest.mark.parametrize('case,sampler', [('seg_ade_k3', 'ddim'), ('seg_city_r2', 'ddim'), ('seg_ddpm', 'ddpm'), ('depth_k3_r2', 'ddim')])
+@pytest.mark.parametrize('case,sampler', [('seg_ade_k3', 'ddim'), ('seg_city_r2', 'ddim'), ('seg_ddpm', 'ddpm'), ('depth_k3_r2', 'ddim'),
+                                          ('depth_td2', 'ddim'), ('bev_fusion', 'ddim'), ('bev_camera', 'ddim')])   # round 6: the depth chain (r = 1), the bev u chain
 def test_sample_as_hip_graph_is_bit_identical(case, sampler):
     """the K-step loop captured in a hipGraph (no host sync, no host memory inside ``ddp_sample``) and
     replayed - same bits as the plain call, on the captured inputs and on NEW inputs copied into the graph's static buffers;
@@ -333,8 +334,10 @@ def test_sample_as_hip_graph_is_bit_identical(case, sampler):
     kw = dict(h=cfg['h'], w=cfg['w'], batch=1, randsteps=cfg['randsteps'], timesteps=cfg['timesteps'], bit_scale=cfg['bit_scale'])
     if task == 'seg':
         kw.update(num_classes=cfg['num_classes'], accumulation=cfg['accumulation'], sampler=sampler)
+    elif task == 'depth':
+        kw.update(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'], time_difference=cfg.get('time_difference', 1))
     else:
-        kw.update(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'])
+        kw.update(num_classes=6, feat_channels=cfg['feat_channels'], bev_input_scope=cfg['input_scope'], bev_output_scope=cfg['output_scope'])
     eng = DDPEngine(sd, task, **kw)
     dx, dn = x.cuda(), noise.unsqueeze(0).cuda()
     dsn = step_noise.unsqueeze(1).contiguous().cuda() if step_noise is not None else None
@@ -344,7 +347,7 @@ def test_sample_as_hip_graph_is_bit_identical(case, sampler):
     assert torch.equal(graph.replay().clone(), plain)
     assert torch.equal(graph.replay().clone(), plain)                  # replays are idempotent
     cm = 1 if task == 'depth' else 256
-    x2, n2 = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], 256, cm, seed=4242)
+    x2, n2 = synthetic.make_inputs(1, cfg['h'], cfg['w'], cfg['randsteps'], cfg.get('feat_channels', 256), cm, seed=4242)
     sn2 = torch.randn_like(dsn) if dsn is not None else None
     want = eng.sample(x2.cuda(), n2.cuda(), sn2).clone()
     assert not torch.equal(want, plain)
