@@ -347,6 +347,33 @@ def test_fused_and_unfused_step_boundary_depth_bev(dev, name):
         assert float(((a > 0.5) == (b > 0.5)).float().mean()) > 0.9995
 
 
+@pytest.mark.parametrize('task,h,w,r', [('depth', 5, 37, 1), ('depth', 9, 11, 2), ('bev', 12, 20, 1), ('bev', 16, 16, 2)])
+def test_depth_bev_batch_equals_independent_runs(dev, task, h, w, r):
+    """The round-6 step heads (k_depth_head, k_bev_q, k_bev_u_update, the tails of k_layer MODE 8 / 9, layer 0 as MODE 10) index
+    tokens of ALL maps of a call; the reference-made fixtures are single-image.  Three images of an odd size in ONE call (token counts
+    that are no multiple of 32: groups straddle images) must give, image by image, the bits of three single-image calls."""
+    from ddp_amd.engine import DDPEngine
+    from ddp_amd.utils import synthetic
+    B = 3
+    if task == 'depth':
+        sd = synthetic.make_state_dict('depth', 1, 6, 256, seed=77)
+        x, noise = synthetic.make_inputs(B, h, w, r, 256, 1, seed=78)
+        kw = dict(h=h, w=w, randsteps=r, timesteps=4, bit_scale=0.1, min_depth=1e-3, max_depth=80.0, device=dev)
+    else:
+        sd = synthetic.make_state_dict('bev', 6, 5, 256, seed=79)
+        x, noise = synthetic.make_inputs(B, h, w, r, 256, 256, seed=80)
+        kw = dict(h=h, w=w, randsteps=r, timesteps=3, bit_scale=0.01, num_classes=6, feat_channels=256, device=dev,
+                  bev_input_scope=[[-51.2, 51.2, 102.4 / h], [-51.2, 51.2, 102.4 / w]],
+                  bev_output_scope=[[-50, 50, 100.0 / (h + 7)], [-50, 50, 100.0 / (w + 9)]])
+    eb = DDPEngine(sd, task, batch=B, **kw)
+    out = eb.sample(x.to(dev), noise.to(dev)).clone()
+    assert torch.isfinite(out).all()
+    e1 = DDPEngine(sd, task, batch=1, **kw)
+    for b in range(B):
+        one = e1.sample(x[b:b + 1].contiguous().to(dev), noise[b:b + 1].contiguous().to(dev))
+        assert torch.equal(one[0], out[b]), f'image {b} differs between the batched and the single-image call'
+
+
 def test_sample_batch_matches_per_image_oracle(dev):
     """B=3 images in ONE call (what the reference cannot do: its loop is b=1) == three independent
     oracle runs, each with its own noise."""
